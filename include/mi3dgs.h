@@ -1,0 +1,167 @@
+/* mi3dgs C-ABI: the MI355X (gfx950) 3D Gaussian Splatting hot path.
+ *
+ * This is the drop-in boundary for the one path of krishan44/pipeline-pointcloud that this
+ * repository accelerates: the `Train-Stage1` component (reference
+ * source/container/src/main.py:1270-1316 single GPU `ns-train splatfacto`, and
+ * main.py:1318-1347 multi GPU `gsplat/examples/simple_trainer.py`).  The reference has no
+ * in-process FFI for that path -- it shells out (pipeline/pipeline.py:217-222) to
+ * third-party CUDA code (gsplat) whose operator surface is what each entry point below
+ * replaces.  The "replaces" notes name that upstream operator and the reference call site
+ * that reaches it.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless it says "host";
+ *   - all tensors are dense, row-major, float32 unless stated; C cameras, N Gaussians;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing
+ *     synchronises the host, nothing allocates: scratch comes in as `workspace`;
+ *   - return 0 on success, non-zero on failure with mi3dgs_last_error() describing it
+ *     (thread-local).  Inputs are borrowed, outputs are written in place.
+ *
+ * Packed records (one 64-byte line each, so the rasteriser's gather and its gradient
+ * atomics cost ONE memory request per (tile, Gaussian)):
+ *   splat record  [C*N][16]: 0 x, 1 y (pixels) | 2,3,4 conic A,B,C | 5 opacity (after
+ *       activation / compensation) | 6,7,8 r,g,b (after SH + 0.5, clamp >= 0) | 9 depth |
+ *       10 compensation | 11..15 zero.           == gsplat means2d/conics/opacities/colors/depths
+ *   grad record   [C*N][16]: 0,1 d/dxy | 2,3,4 d/dconic | 5 d/dopacity | 6,7,8 d/drgb |
+ *       9,10 sum |d/dxy| (absgrad) | 11 d/ddepth (input to project_bwd) | 12..15 unused.
+ */
+#ifndef MI3DGS_H
+#define MI3DGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI3DGS_SPLAT_STRIDE 16
+#define MI3DGS_GRAD_STRIDE 16
+
+/* `flags` bits of project_fwd / project_bwd */
+#define MI3DGS_FLAG_LOG_SCALES 1   /* scales are log-space parameters; exp() fused */
+#define MI3DGS_FLAG_LOGIT_OPAC 2   /* opacities are logits; sigmoid() fused */
+#define MI3DGS_FLAG_ANTIALIASED 4  /* rasterize_mode "antialiased": opacity *= compensation */
+
+/* colour modes of project_fwd / project_bwd */
+#define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
+#define MI3DGS_COLOR_PER_GAUSSIAN 1 /* colors[N,3] */
+#define MI3DGS_COLOR_PER_CAMERA 2  /* colors[C,N,3] */
+
+const char* mi3dgs_last_error(void);
+int mi3dgs_abi_version(void);
+int mi3dgs_splat_stride(void);
+int mi3dgs_grad_stride(void);
+
+/* ---- per-Gaussian stage --------------------------------------------------------------
+ * Replaces gsplat fully_fused_projection_fwd + quat_scale_to_covar_preci +
+ * spherical_harmonics_fwd + the exp/sigmoid/clamp glue of gsplat.rasterization()
+ * (reached via main.py:1312 `ns-train`, main.py:1343 `simple_trainer.py`).
+ * viewmats[C,4,4] world->camera, Ks[C,3,3]; radii[C*N,2] int32 (0,0 = culled). */
+int mi3dgs_project_fwd(int C, int N, const float* means, const float* quats, const float* scales,
+                       const float* opacities /* nullable */, const float* sh0, const float* shN,
+                       const float* colors, int color_mode, int sh_degree, const float* viewmats,
+                       const float* Ks, int width, int height, float eps2d, float near_plane,
+                       float far_plane, float radius_clip, int flags, int32_t* radii, float* splats,
+                       void* stream);
+
+/* Replaces fully_fused_projection_bwd + spherical_harmonics_bwd + the autograd of the
+ * glue.  v_splats is the packed gradient record written by rasterize_bwd.  Every output is
+ * written once (sum over cameras inside the kernel, no atomics).  stat_* (nullable,
+ * accumulated in place) are gsplat DefaultStrategy._update_state's running statistics:
+ * screen-space gradient norm (from |d/dxy| when stat_use_abs), visibility count, max
+ * normalised screen radius. */
+int mi3dgs_project_bwd(int C, int N, const float* means, const float* quats, const float* scales,
+                       const float* opacities, const float* sh0, const float* shN, int color_mode,
+                       int sh_degree, const float* viewmats, const float* Ks, int width, int height,
+                       float eps2d, int flags, const int32_t* radii, const float* splats,
+                       const float* v_splats, float* v_means, float* v_quats, float* v_scales,
+                       float* v_opacities /* nullable */, float* v_sh0, float* v_shN,
+                       float* v_colors /* nullable */, float* stat_grad2d, float* stat_count,
+                       float* stat_radii, int stat_use_abs, void* stream);
+
+/* ---- tile binning --------------------------------------------------------------------
+ * Replaces gsplat isect_tiles (count + emit + cub radix sort) and isect_offset_encode.
+ * Two phases so that the caller may read the intersection count back between them (exact
+ * allocation) or skip the read-back and size flatten_ids / tile_keys by capacity
+ * (`max_isect`): every kernel takes its live count from n_isect_dev[0] on the device. */
+size_t mi3dgs_bin_workspace_bytes(int C, int N, long long max_isect);
+int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float* splats, int tile_size,
+                     int tile_width, int tile_height, int32_t* tiles_per_gauss /* [C*N], nullable */,
+                     int32_t* n_isect_dev /* [1] */, void* workspace, size_t workspace_bytes,
+                     long long max_isect, void* stream);
+/* flatten_ids[max_isect] (index into the C*N records, sorted by (camera, tile, depth)),
+ * tile_keys[max_isect] (camera*tiles + tile), isect_offsets[C*tile_height*tile_width],
+ * isect_ids_opt[max_isect] int64 (nullable): gsplat's (tile << 32 | depth bits) keys. */
+int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int tile_size,
+                    int tile_width, int tile_height, const int32_t* n_isect_dev, long long max_isect,
+                    int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
+                    int64_t* isect_ids_opt, void* workspace, size_t workspace_bytes, void* stream);
+
+/* building blocks of the above, exported for reuse and for tests */
+size_t mi3dgs_sort_workspace_bytes(long long n);
+int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits, void* workspace,
+                          size_t workspace_bytes, void* stream); /* stable, ascending, in place */
+size_t mi3dgs_scan_workspace_bytes(long long n);
+int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long long n,
+                              uint32_t* total_dev /* nullable */, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* ---- rasteriser ----------------------------------------------------------------------
+ * Replaces gsplat rasterize_to_pixels_fwd / _bwd.  tile_size must be 16.
+ * render[C,H,W,3], alphas[C,H,W,1], last_ids[C,H,W] int32; backgrounds[C,3] nullable. */
+int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_width,
+                         int tile_height, const float* splats, const int32_t* isect_offsets,
+                         const int32_t* flatten_ids, const int32_t* n_isect_dev,
+                         const float* backgrounds, float* render, float* alphas, int32_t* last_ids,
+                         void* stream);
+/* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it. */
+int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width,
+                         int tile_height, const float* splats, const int32_t* isect_offsets,
+                         const int32_t* flatten_ids, const int32_t* n_isect_dev,
+                         const float* backgrounds, const float* alphas, const int32_t* last_ids,
+                         const float* v_render, const float* v_alphas, int absgrad, float* v_splats,
+                         void* stream);
+
+/* ---- loss ----------------------------------------------------------------------------
+ * Replaces the L1 + SSIM(11x11, sigma 1.5) loss of splatfacto / simple_trainer.
+ * sums[2] (zeroed by the caller) receives {sum |r-t|, sum SSIM map}; the three dm_* maps
+ * [C,H,W,3] are scratch handed from fwd to bwd. */
+int mi3dgs_loss_fwd(int C, int height, int width, const float* render, const float* target,
+                    float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream);
+int mi3dgs_loss_bwd(int C, int height, int width, const float* render, const float* target,
+                    const float* dm_dmu1, const float* dm_dsigma1, const float* dm_dsigma12,
+                    float ssim_lambda, float loss_scale, float* v_render, void* stream);
+/* splatfacto use_scale_regularization (reference main.py:1288): loss_sum[0] (nullable) +=
+ * weight*mean(max(ratio,max_ratio)-max_ratio); v_scales (nullable, log-space) accumulated. */
+int mi3dgs_scale_reg(int N, const float* scales_log, float weight, float max_ratio, float* v_scales,
+                     float* loss_sum, void* stream);
+
+/* ---- optimiser -----------------------------------------------------------------------
+ * Replaces torch.optim.Adam over the Gaussian parameter groups: one launch for up to 8
+ * flat segments.  The pointer arrays are HOST arrays of device pointers. */
+int mi3dgs_adam_step(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long long* numel, const float* lrs, int step,
+                     float beta1, float beta2, float eps, void* stream);
+
+/* ---- adaptive density control --------------------------------------------------------
+ * Replaces gsplat DefaultStrategy._grow_gs/_prune_gs and strategy.ops duplicate / split /
+ * remove / reset_opa.  decide -> mi3dgs_scan_exclusive_u32(out_count) -> scatter.
+ * Group order everywhere: means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45]. */
+int mi3dgs_densify_decide(int N, const float* scales_log, const float* opacities_logit,
+                          const float* stat_grad2d, const float* stat_count, float grow_grad2d,
+                          float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs,
+                          int do_grow, int check_too_big, uint8_t* flags, uint32_t* out_count,
+                          void* stream);
+int mi3dgs_densify_scatter(int N, const float* const* params_in, const float* const* exp_avg_in,
+                           const float* const* exp_avg_sq_in, float* const* params_out,
+                           float* const* exp_avg_out, float* const* exp_avg_sq_out,
+                           const uint8_t* flags, const uint32_t* offsets, long long capacity,
+                           uint32_t seed, void* stream);
+int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_logit, float* exp_avg,
+                         float* exp_avg_sq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI3DGS_H */

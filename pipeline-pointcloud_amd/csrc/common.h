@@ -1,0 +1,97 @@
+// Shared helpers for the mi3dgs HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI_WAVE 64
+
+// ---- splat record: one 64-byte line per (camera, Gaussian), written by project_fwd and
+// gathered (one HBM/L2 request each) by the rasteriser.  See DESIGN.md "Data layout".
+#define SPLAT_STRIDE 16
+#define SP_X 0
+#define SP_Y 1
+#define SP_CA 2
+#define SP_CB 3
+#define SP_CC 4
+#define SP_OPA 5
+#define SP_R 6
+#define SP_G 7
+#define SP_B 8
+#define SP_DEPTH 9
+#define SP_COMP 10
+
+// ---- gradient record: one 64-byte line per (camera, Gaussian), accumulated by
+// rasterize_bwd with float atomics (one 64-B atomic request per (tile, Gaussian)).
+#define GRAD_STRIDE 16
+#define GR_X 0
+#define GR_Y 1
+#define GR_CA 2
+#define GR_CB 3
+#define GR_CC 4
+#define GR_OPA 5
+#define GR_R 6
+#define GR_G 7
+#define GR_B 8
+#define GR_ABSX 9
+#define GR_ABSY 10
+#define GR_DEPTH 11
+
+#define MI_FLAG_LOG_SCALES 1      // scales are log-space parameters (exp applied in-kernel)
+#define MI_FLAG_LOGIT_OPAC 2      // opacities are logits (sigmoid applied in-kernel)
+#define MI_FLAG_ANTIALIASED 4     // rasterize_mode == "antialiased": opacity *= compensation
+
+#define ALPHA_THRESHOLD (1.0f / 255.0f)
+#define MAX_ALPHA 0.999f
+#define T_STOP 1e-4f
+
+int mi_set_error(const char* what, hipError_t e, const char* file, int line);
+int mi_set_error_msg(const char* msg);
+
+#define MI_LAUNCH_CHECK()                                                            \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) return mi_set_error("launch", e__, __FILE__, __LINE__); \
+    } while (0)
+
+#define MI_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) return mi_set_error(#call, e__, __FILE__, __LINE__); \
+    } while (0)
+
+#define MI_REQUIRE(cond, msg)                        \
+    do {                                             \
+        if (!(cond)) return mi_set_error_msg(msg);   \
+    } while (0)
+
+static inline int mi_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions via DPP (no LDS traffic).  Result valid in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    // row_bcast:15 into rows 1 and 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));
+    // row_bcast:31 into rows 2 and 3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, true));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+    v = wave_sum_to_lane63(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ unsigned wave_sum_all_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

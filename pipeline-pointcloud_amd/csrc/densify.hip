@@ -1,0 +1,191 @@
+// Adaptive density control (densify / prune / opacity reset) with optimiser-state surgery,
+// on device.  gfx950 only.
+//
+// Replaces gsplat DefaultStrategy._grow_gs / _prune_gs / reset_opa and the torch
+// cat/index/zeros optimiser surgery of gsplat.strategy.ops (duplicate, split, remove,
+// reset_opa), reached by the reference through main.py:1312 / main.py:1343
+// (SURVEY.md 8a row a13).  Decision rule, per Gaussian with running stats (grad2d, count):
+//   g = grad2d / max(count, 1);  high = g > grow_grad2d
+//   small = max(exp(scale)) <= grow_scale3d * scene_scale
+//   duplicate = high & small        -> original keeps its Adam state, copy gets zeros
+//   split     = high & !small       -> original replaced by 2 samples, scale / 1.6, zero state
+//   prune (evaluated on the grown set, as upstream does): sigmoid(opacity) < prune_opa,
+//          or (step > reset_every and max(exp(scale)) > prune_scale3d * scene_scale)
+// The pass is: decide -> exclusive scan of output counts -> scatter into fresh buffers.
+// Output order: survivors keep their relative order, children sit next to their parent
+// (upstream appends them at the end; the order only breaks exact-depth ties).
+//
+// Bound: HBM streaming, (59 params + 2*59 Adam moments) * 4 B read and written per survivor;
+// runs every 100 steps.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    uint32_t state = x * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+// two independent N(0,1) samples from a counter
+__device__ __forceinline__ void randn2(uint32_t seed, uint32_t ctr, float& a, float& b) {
+    uint32_t h1 = pcg_hash(seed ^ pcg_hash(ctr * 2u + 0u));
+    uint32_t h2 = pcg_hash(seed ^ pcg_hash(ctr * 2u + 1u));
+    float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+    float r = sqrtf(-2.f * __logf(u1));
+    float s, c;
+    __sincosf(6.283185307179586f * u2, &s, &c);
+    a = r * c; b = r * s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// flags: bit0 duplicate, bit1 split, bit2 prune
+__global__ __launch_bounds__(256) void densify_decide_kernel(
+    int N, const float* __restrict__ scales_log, const float* __restrict__ opac_logit,
+    const float* __restrict__ stat_grad2d, const float* __restrict__ stat_count, float grow_grad2d,
+    float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs, int do_grow, int check_too_big,
+    uint8_t* __restrict__ flags, uint32_t* __restrict__ out_count) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float smax = __expf(fmaxf(scales_log[3 * n], fmaxf(scales_log[3 * n + 1], scales_log[3 * n + 2])));
+    bool dup = false, split = false;
+    if (do_grow) {
+        float g = stat_grad2d[n] / fmaxf(stat_count[n], 1.f);
+        bool high = g > grow_grad2d;
+        bool small = smax <= grow_scale3d_abs;
+        dup = high && small;
+        split = high && !small;
+    }
+    float s_eff = split ? smax / 1.6f : smax;
+    bool prune = sigmoidf_(opac_logit[n]) < prune_opa;
+    if (check_too_big) prune = prune || (s_eff > prune_scale3d_abs);
+    flags[n] = (uint8_t)((dup ? 1 : 0) | (split ? 2 : 0) | (prune ? 4 : 0));
+    out_count[n] = prune ? 0u : ((dup || split) ? 2u : 1u);
+}
+
+struct DensifyBufs {
+    const float* in[6];     // means, quats, scales, opacities, sh0, shN
+    const float* in_m[6];
+    const float* in_v[6];
+    float* out[6];
+    float* out_m[6];
+    float* out_v[6];
+};
+
+__device__ __forceinline__ void copy_row(const float* __restrict__ src, float* __restrict__ dst, int w) {
+    for (int i = 0; i < w; i++) dst[i] = src[i];
+}
+__device__ __forceinline__ void zero_row(float* __restrict__ dst, int w) {
+    for (int i = 0; i < w; i++) dst[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void densify_scatter_kernel(int N, DensifyBufs b, const uint8_t* __restrict__ flags,
+                                                              const uint32_t* __restrict__ offsets, uint32_t cap,
+                                                              uint32_t seed) {
+    const int widths[6] = {3, 4, 3, 1, 3, 45};
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    uint8_t f = flags[n];
+    if (f & 4) return;
+    uint32_t o = offsets[n];
+    bool dup = f & 1, split = f & 2;
+    int copies = (dup || split) ? 2 : 1;
+    if (o + copies > cap) return;   // capacity guard; the host checks the total first
+    for (int c = 0; c < copies; c++) {
+        bool keep_state = !split && c == 0;
+        for (int g = 0; g < 6; g++) {
+            int w = widths[g];
+            const float* src = b.in[g] + (size_t)n * w;
+            float* dst = b.out[g] + (size_t)(o + c) * w;
+            copy_row(src, dst, w);
+            float* dm = b.out_m[g] + (size_t)(o + c) * w;
+            float* dv = b.out_v[g] + (size_t)(o + c) * w;
+            if (keep_state) {
+                copy_row(b.in_m[g] + (size_t)n * w, dm, w);
+                copy_row(b.in_v[g] + (size_t)n * w, dv, w);
+            } else {
+                zero_row(dm, w);
+                zero_row(dv, w);
+            }
+        }
+        if (split) {
+            // sample = R(q) * (exp(s) .* randn(3)); mean += sample; s = log(exp(s) / 1.6)
+            const float* q = b.in[1] + (size_t)n * 4;
+            float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+            float inv = rsqrtf(fmaxf(n2, 1e-24f));
+            float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+            float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
+                          2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                          2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
+            const float* sl = b.in[2] + (size_t)n * 3;
+            float r0, r1, r2, r3;
+            randn2(seed, (uint32_t)n * 4u + (uint32_t)c * 2u, r0, r1);
+            randn2(seed, (uint32_t)n * 4u + (uint32_t)c * 2u + 1u, r2, r3);
+            float e[3] = {__expf(sl[0]) * r0, __expf(sl[1]) * r1, __expf(sl[2]) * r2};
+            float* mo = b.out[0] + (size_t)(o + c) * 3;
+            float* so = b.out[2] + (size_t)(o + c) * 3;
+            for (int i = 0; i < 3; i++) {
+                mo[i] += R[3 * i] * e[0] + R[3 * i + 1] * e[1] + R[3 * i + 2] * e[2];
+                so[i] = sl[i] - 0.47000362924573563f;   // log(1.6)
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reset_opacity_kernel(int N, float* __restrict__ opac_logit, float max_logit,
+                                                            float* __restrict__ m, float* __restrict__ v) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    opac_logit[n] = fminf(opac_logit[n], max_logit);
+    m[n] = 0.f;
+    v[n] = 0.f;
+}
+
+}  // namespace
+
+// Step 1: decision flags + per-Gaussian output counts.
+extern "C" int mi3dgs_densify_decide(int N, const float* scales_log, const float* opacities_logit,
+                                     const float* stat_grad2d, const float* stat_count, float grow_grad2d,
+                                     float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs, int do_grow,
+                                     int check_too_big, uint8_t* flags, uint32_t* out_count, void* stream) {
+    if (N <= 0) return 0;
+    MI_REQUIRE(!do_grow || (stat_grad2d && stat_count), "densify_decide: growing needs the running statistics");
+    hipLaunchKernelGGL(densify_decide_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
+                       opacities_logit, stat_grad2d, stat_count, grow_grad2d, grow_scale3d_abs, prune_opa,
+                       prune_scale3d_abs, do_grow, check_too_big, flags, out_count);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// Step 2 (after mi3dgs_scan_exclusive_u32 over out_count): scatter parameters and Adam
+// moments of the 6 groups {means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45]}
+// into fresh buffers of `capacity` Gaussians.
+extern "C" int mi3dgs_densify_scatter(int N, const float* const* params_in, const float* const* exp_avg_in,
+                                      const float* const* exp_avg_sq_in, float* const* params_out,
+                                      float* const* exp_avg_out, float* const* exp_avg_sq_out, const uint8_t* flags,
+                                      const uint32_t* offsets, long long capacity, uint32_t seed, void* stream) {
+    if (N <= 0) return 0;
+    DensifyBufs b;
+    for (int g = 0; g < 6; g++) {
+        b.in[g] = params_in[g]; b.in_m[g] = exp_avg_in[g]; b.in_v[g] = exp_avg_sq_in[g];
+        b.out[g] = params_out[g]; b.out_m[g] = exp_avg_out[g]; b.out_v[g] = exp_avg_sq_out[g];
+        MI_REQUIRE(b.in[g] && b.in_m[g] && b.in_v[g] && b.out[g] && b.out_m[g] && b.out_v[g],
+                   "densify_scatter: null buffer");
+    }
+    hipLaunchKernelGGL(densify_scatter_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, b, flags,
+                       offsets, (uint32_t)capacity, seed);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// opacities <- min(opacities, max_logit); Adam moments of the opacity group zeroed.
+extern "C" int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_logit, float* exp_avg, float* exp_avg_sq,
+                                    void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(reset_opacity_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                       opacities_logit, max_logit, exp_avg, exp_avg_sq);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

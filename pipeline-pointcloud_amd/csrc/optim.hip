@@ -1,0 +1,148 @@
+// Fused Adam over all Gaussian parameter groups in ONE launch, plus the splatfacto scale
+// regulariser.  gfx950 only.
+//
+// Replaces torch.optim.Adam (one foreach launch set per group in splatfacto / gsplat's
+// simple_trainer) reached by the reference through main.py:1312 / main.py:1343, and the
+// `use_scale_regularization=True` term the reference passes at main.py:1288
+// (SURVEY.md 8a rows a11-a12).
+//
+// Bound: pure HBM stream, 28 B per parameter float (read p,g,m,v; write p,m,v)
+// = 1652 B per Gaussian at 59 floats.
+#include "common.h"
+#include <math.h>
+
+#define MI_ADAM_MAX_SEGS 8
+
+struct AdamSeg {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;       // floats in this segment
+    float lr;
+    int first_block;   // filled by the host wrapper
+};
+
+struct AdamArgs {
+    AdamSeg seg[MI_ADAM_MAX_SEGS];
+    int nseg;
+};
+
+namespace {
+
+constexpr int AD_THREADS = 256;
+constexpr int AD_PER_BLOCK = AD_THREADS * 4 * 4;   // 4 float4 per thread
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float b1, float b2,
+                                      float inv_bc2_sqrt, float eps) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p -= step_size * m / denom;
+}
+
+__global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, float b2, float eps, float inv_bc1,
+                                                          float inv_bc2_sqrt) {
+    int blk = blockIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MI_ADAM_MAX_SEGS; i++)
+        if (i < a.nseg && blk >= a.seg[i].first_block) s = i;
+    const AdamSeg sg = a.seg[s];
+    long long base = (long long)(blk - sg.first_block) * AD_PER_BLOCK;
+    float step_size = sg.lr * inv_bc1;
+    bool aligned = ((((uintptr_t)sg.p) | ((uintptr_t)sg.g) | ((uintptr_t)sg.m) | ((uintptr_t)sg.v)) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        long long i = base + ((long long)it * AD_THREADS + threadIdx.x) * 4;
+        if (i >= sg.n) break;
+        if (aligned && i + 4 <= sg.n) {
+            float4 p = *reinterpret_cast<float4*>(sg.p + i);
+            float4 g = *reinterpret_cast<const float4*>(sg.g + i);
+            float4 m = *reinterpret_cast<float4*>(sg.m + i);
+            float4 v = *reinterpret_cast<float4*>(sg.v + i);
+            adam1(p.x, g.x, m.x, v.x, step_size, b1, b2, inv_bc2_sqrt, eps);
+            adam1(p.y, g.y, m.y, v.y, step_size, b1, b2, inv_bc2_sqrt, eps);
+            adam1(p.z, g.z, m.z, v.z, step_size, b1, b2, inv_bc2_sqrt, eps);
+            adam1(p.w, g.w, m.w, v.w, step_size, b1, b2, inv_bc2_sqrt, eps);
+            *reinterpret_cast<float4*>(sg.p + i) = p;
+            *reinterpret_cast<float4*>(sg.m + i) = m;
+            *reinterpret_cast<float4*>(sg.v + i) = v;
+        } else {
+            for (int k = 0; k < 4 && i + k < sg.n; k++) {
+                float p = sg.p[i + k], m = sg.m[i + k], v = sg.v[i + k];
+                adam1(p, sg.g[i + k], m, v, step_size, b1, b2, inv_bc2_sqrt, eps);
+                sg.p[i + k] = p; sg.m[i + k] = m; sg.v[i + k] = v;
+            }
+        }
+    }
+}
+
+// loss += weight * mean(max(smax/smin, max_ratio) - max_ratio); v_scales (log-space) += d/ds
+__global__ __launch_bounds__(256) void scale_reg_kernel(int N, const float* __restrict__ scales_log, float weight,
+                                                        float max_ratio, float* __restrict__ v_scales,
+                                                        float* __restrict__ loss_sum) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    float contrib = 0.f;
+    if (n < N) {
+        float s0 = scales_log[3 * n], s1 = scales_log[3 * n + 1], s2 = scales_log[3 * n + 2];
+        float mx = fmaxf(s0, fmaxf(s1, s2)), mn = fminf(s0, fminf(s1, s2));
+        float ratio = __expf(mx - mn);
+        if (ratio > max_ratio) {
+            contrib = ratio - max_ratio;
+            if (v_scales) {
+                float g = weight * ratio / (float)N;
+                // torch amax/amin backward: gradient split evenly between ties
+                int nmx = (s0 == mx) + (s1 == mx) + (s2 == mx);
+                int nmn = (s0 == mn) + (s1 == mn) + (s2 == mn);
+                float gm = g / (float)nmx, gn = g / (float)nmn;
+                v_scales[3 * n] += (s0 == mx ? gm : 0.f) - (s0 == mn ? gn : 0.f);
+                v_scales[3 * n + 1] += (s1 == mx ? gm : 0.f) - (s1 == mn ? gn : 0.f);
+                v_scales[3 * n + 2] += (s2 == mx ? gm : 0.f) - (s2 == mn ? gn : 0.f);
+            }
+        }
+    }
+    if (loss_sum) {
+        contrib = wave_sum_all(contrib);
+        if (lane_id() == 0 && contrib != 0.f) atomicAdd(loss_sum, contrib * weight / (float)N);
+    }
+}
+
+}  // namespace
+
+// One Adam step (torch.optim.Adam semantics, no weight decay / amsgrad) over up to 8 flat
+// float segments.  `step` is the 1-based step count after increment.
+extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                                float* const* exp_avg_sq, const long long* numel, const float* lrs, int step,
+                                float beta1, float beta2, float eps, void* stream) {
+    MI_REQUIRE(nseg >= 1 && nseg <= MI_ADAM_MAX_SEGS, "adam_step: 1..8 segments");
+    MI_REQUIRE(step >= 1, "adam_step: step is 1-based");
+    AdamArgs a;
+    a.nseg = nseg;
+    int blocks = 0;
+    for (int i = 0; i < MI_ADAM_MAX_SEGS; i++) {
+        if (i < nseg) {
+            MI_REQUIRE(numel[i] >= 0, "adam_step: negative numel");
+            a.seg[i] = AdamSeg{params[i], grads[i], exp_avg[i], exp_avg_sq[i], numel[i], lrs[i], blocks};
+            blocks += mi_div_up(numel[i], AD_PER_BLOCK);
+        } else {
+            a.seg[i] = AdamSeg{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0x7fffffff};
+        }
+    }
+    if (blocks == 0) return 0;
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(AD_THREADS), 0, (hipStream_t)stream, a, beta1, beta2, eps,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_scale_reg(int N, const float* scales_log, float weight, float max_ratio, float* v_scales,
+                                float* loss_sum, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(scale_reg_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
+                       weight, max_ratio, v_scales, loss_sum);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,551 @@
+// Fused per-Gaussian stage of the 3DGS hot path: activations -> quat/scale covariance ->
+// EWA projection -> cull -> SH colour, forward and backward.  gfx950 only.
+//
+// Replaces (reference reaches these only through main.py:1312 / main.py:1343):
+//   gsplat fully_fused_projection_{fwd,bwd}, quat_scale_to_covar_preci,
+//   spherical_harmonics_{fwd,bwd}, and the torch.exp / torch.sigmoid / clamp(+0.5) glue
+//   around them.
+//
+// Roofline: HBM streaming.  One thread per (camera, Gaussian) forward; one thread per
+// Gaussian (looping cameras, no atomics) backward.  Algorithmic bytes: forward
+// 44 B (+192 B SH when visible) read + 72 B written per visible Gaussian; backward
+// 236 + 64 B read, 236 B written.
+#include "common.h"
+
+namespace {
+
+struct Cam {
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ viewmats, const float* __restrict__ Ks, int c) {
+    Cam cam;
+    const float* V = viewmats + 16 * c;
+    const float* K = Ks + 9 * c;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) cam.R[3 * i + j] = V[4 * i + j];
+        cam.t[i] = V[4 * i + 3];
+    }
+    cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+    return cam;
+}
+
+__device__ __forceinline__ void quat_to_rotmat(const float q[4], float R[9], float& inv_norm) {
+    float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    inv_norm = rsqrtf(fmaxf(n2, 1e-24f));
+    float w = q[0] * inv_norm, x = q[1] * inv_norm, y = q[2] * inv_norm, z = q[3] * inv_norm;
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z); R[2] = 2.f * (x * z + w * y);
+    R[3] = 2.f * (x * y + w * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
+    R[6] = 2.f * (x * z - w * y); R[7] = 2.f * (y * z + w * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R S)(R S)^T, symmetric 3x3 stored full.
+__device__ __forceinline__ void covar_world(const float R[9], const float s[3], float S[9]) {
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[3 * i + j] = R[3 * i + j] * s[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            S[3 * i + j] = M[3 * i] * M[3 * j] + M[3 * i + 1] * M[3 * j + 1] + M[3 * i + 2] * M[3 * j + 2];
+}
+
+// A(3x3) * B(3x3)
+__device__ __forceinline__ void mat3_mul(const float A[9], const float B[9], float Cm[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Cm[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// A * B^T
+__device__ __forceinline__ void mat3_mul_bt(const float A[9], const float B[9], float Cm[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Cm[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+// A^T * B
+__device__ __forceinline__ void mat3_mul_at(const float A[9], const float B[9], float Cm[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            Cm[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+struct Proj {
+    float mc[3];        // camera-space mean
+    float Sc[9];        // camera-space covariance
+    float J[6];         // 2x3 Jacobian
+    float tx, ty;
+    bool x_in, y_in;
+    float a, b, c;      // blurred 2-D covariance
+    float det, det_orig, comp;
+    float conA, conB, conC;
+    float m2x, m2y;
+};
+
+__device__ __forceinline__ void project_core(const Cam& cam, const float mean[3], const float Sw[9],
+                                             int W, int H, float eps2d, Proj& P) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        P.mc[i] = cam.R[3 * i] * mean[0] + cam.R[3 * i + 1] * mean[1] + cam.R[3 * i + 2] * mean[2] + cam.t[i];
+    float tmp[9];
+    mat3_mul(cam.R, Sw, tmp);
+    mat3_mul_bt(tmp, cam.R, P.Sc);
+    float x = P.mc[0], y = P.mc[1], z = P.mc[2];
+    float rz = 1.f / z, rz2 = rz * rz;
+    float tan_fovx = 0.5f * W / cam.fx, tan_fovy = 0.5f * H / cam.fy;
+    float lim_x_pos = (W - cam.cx) / cam.fx + 0.3f * tan_fovx;
+    float lim_x_neg = cam.cx / cam.fx + 0.3f * tan_fovx;
+    float lim_y_pos = (H - cam.cy) / cam.fy + 0.3f * tan_fovy;
+    float lim_y_neg = cam.cy / cam.fy + 0.3f * tan_fovy;
+    float xz = x * rz, yz = y * rz;
+    P.x_in = (xz <= lim_x_pos) && (xz >= -lim_x_neg);
+    P.y_in = (yz <= lim_y_pos) && (yz >= -lim_y_neg);
+    P.tx = z * fminf(lim_x_pos, fmaxf(-lim_x_neg, xz));
+    P.ty = z * fminf(lim_y_pos, fmaxf(-lim_y_neg, yz));
+    P.J[0] = cam.fx * rz; P.J[1] = 0.f; P.J[2] = -cam.fx * P.tx * rz2;
+    P.J[3] = 0.f; P.J[4] = cam.fy * rz; P.J[5] = -cam.fy * P.ty * rz2;
+    // cov2d = J Sc J^T
+    float JS[6];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            JS[3 * i + j] = P.J[3 * i] * P.Sc[j] + P.J[3 * i + 1] * P.Sc[3 + j] + P.J[3 * i + 2] * P.Sc[6 + j];
+    float a0 = JS[0] * P.J[0] + JS[1] * P.J[1] + JS[2] * P.J[2];
+    float b0 = JS[0] * P.J[3] + JS[1] * P.J[4] + JS[2] * P.J[5];
+    float c0 = JS[3] * P.J[3] + JS[4] * P.J[4] + JS[5] * P.J[5];
+    P.det_orig = a0 * c0 - b0 * b0;
+    P.a = a0 + eps2d; P.b = b0; P.c = c0 + eps2d;
+    P.det = P.a * P.c - P.b * P.b;
+    P.comp = sqrtf(fmaxf(0.f, P.det_orig / P.det));
+    float rdet = 1.f / P.det;
+    P.conA = P.c * rdet; P.conB = -P.b * rdet; P.conC = P.a * rdet;
+    P.m2x = cam.fx * x * rz + cam.cx;
+    P.m2y = cam.fy * y * rz + cam.cy;
+}
+
+constexpr float SH_C0 = 0.2820947917738781f;
+constexpr float SH_C1 = 0.48860251190292f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+// basis b[0..nb) for unit direction (x,y,z)
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16]) {
+    b[0] = SH_C0;
+    if (deg >= 1) { b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x; }
+    if (deg >= 2) {
+        float xx = x * x, yy = y * y, zz = z * z;
+        b[4] = SH_C2_0 * x * y; b[5] = SH_C2_1 * y * z; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+        b[7] = SH_C2_3 * x * z; b[8] = SH_C2_4 * (xx - yy);
+        if (deg >= 3) {
+            b[9] = SH_C3_0 * y * (3.f * xx - yy); b[10] = SH_C3_1 * x * y * z;
+            b[11] = SH_C3_2 * y * (4.f * zz - xx - yy); b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = SH_C3_4 * x * (4.f * zz - xx - yy); b[14] = SH_C3_5 * z * (xx - yy);
+            b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+        }
+    }
+}
+
+// d(basis)/d(x,y,z) contracted with per-basis weights g[k] (= sum_ch v_rgb[ch]*coef[k][ch])
+__device__ __forceinline__ void sh_basis_vjp(int deg, float x, float y, float z, const float g[16], float vd[3]) {
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (deg >= 1) { vy += -SH_C1 * g[1]; vz += SH_C1 * g[2]; vx += -SH_C1 * g[3]; }
+    if (deg >= 2) {
+        vx += SH_C2_0 * y * g[4]; vy += SH_C2_0 * x * g[4];
+        vy += SH_C2_1 * z * g[5]; vz += SH_C2_1 * y * g[5];
+        vx += SH_C2_2 * -2.f * x * g[6]; vy += SH_C2_2 * -2.f * y * g[6]; vz += SH_C2_2 * 4.f * z * g[6];
+        vx += SH_C2_3 * z * g[7]; vz += SH_C2_3 * x * g[7];
+        vx += SH_C2_4 * 2.f * x * g[8]; vy += SH_C2_4 * -2.f * y * g[8];
+        if (deg >= 3) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            // b9 = C*y*(3xx-yy)
+            vx += SH_C3_0 * 6.f * x * y * g[9]; vy += SH_C3_0 * (3.f * xx - 3.f * yy) * g[9];
+            // b10 = C*xyz
+            vx += SH_C3_1 * y * z * g[10]; vy += SH_C3_1 * x * z * g[10]; vz += SH_C3_1 * x * y * g[10];
+            // b11 = C*y*(4zz-xx-yy)
+            vx += SH_C3_2 * -2.f * x * y * g[11]; vy += SH_C3_2 * (4.f * zz - xx - 3.f * yy) * g[11];
+            vz += SH_C3_2 * 8.f * y * z * g[11];
+            // b12 = C*z*(2zz-3xx-3yy)
+            vx += SH_C3_3 * -6.f * x * z * g[12]; vy += SH_C3_3 * -6.f * y * z * g[12];
+            vz += SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * g[12];
+            // b13 = C*x*(4zz-xx-yy)
+            vx += SH_C3_4 * (4.f * zz - 3.f * xx - yy) * g[13]; vy += SH_C3_4 * -2.f * x * y * g[13];
+            vz += SH_C3_4 * 8.f * x * z * g[13];
+            // b14 = C*z*(xx-yy)
+            vx += SH_C3_5 * 2.f * x * z * g[14]; vy += SH_C3_5 * -2.f * y * z * g[14]; vz += SH_C3_5 * (xx - yy) * g[14];
+            // b15 = C*x*(xx-3yy)
+            vx += SH_C3_6 * (3.f * xx - 3.f * yy) * g[15]; vy += SH_C3_6 * -6.f * x * y * g[15];
+        }
+    }
+    vd[0] = vx; vd[1] = vy; vd[2] = vz;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// --------------------------------------------------------------------------- forward
+// color_mode: 0 = SH (sh0[N,3] + shN[N,15,3]), 1 = colors[N,3], 2 = colors[C,N,3]
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int C, int N, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ sh0, const float* __restrict__ shN, const float* __restrict__ colors,
+    int color_mode, int sh_degree, const float* __restrict__ viewmats, const float* __restrict__ Ks,
+    int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip, int flags,
+    int32_t* __restrict__ radii, float* __restrict__ splats) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)C * N) return;
+    int c = (int)(idx / N);
+    int n = (int)(idx - (long long)c * N);
+    float4* rec = reinterpret_cast<float4*>(splats + idx * SPLAT_STRIDE);
+    int2* rad = reinterpret_cast<int2*>(radii + idx * 2);
+
+    Cam cam = load_cam(viewmats, Ks, c);
+    float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    float zc = cam.R[6] * mean[0] + cam.R[7] * mean[1] + cam.R[8] * mean[2] + cam.t[2];
+    bool ok = (zc >= near_plane) && (zc <= far_plane);
+    Proj P;
+    float opa = 1.f;
+    float rx = 0.f, ry = 0.f;
+    if (ok) {
+        float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+        float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+        if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
+        float Rq[9], inv_norm, Sw[9];
+        quat_to_rotmat(q, Rq, inv_norm);
+        covar_world(Rq, s, Sw);
+        project_core(cam, mean, Sw, W, H, eps2d, P);
+        ok = P.det > 0.f;
+        float extend = 3.33f;
+        if (ok && opacities != nullptr) {
+            opa = opacities[n];
+            if (flags & MI_FLAG_LOGIT_OPAC) opa = sigmoidf(opa);
+            if (flags & MI_FLAG_ANTIALIASED) opa *= P.comp;
+            if (opa < ALPHA_THRESHOLD) ok = false;
+            else extend = fminf(extend, sqrtf(2.0f * __logf(opa / ALPHA_THRESHOLD)));
+        }
+        if (ok) {
+            float bm = 0.5f * (P.a + P.c);
+            float v1 = bm + sqrtf(fmaxf(0.01f, bm * bm - P.det));
+            float r1 = extend * sqrtf(v1);
+            rx = ceilf(fminf(extend * sqrtf(P.a), r1));
+            ry = ceilf(fminf(extend * sqrtf(P.c), r1));
+            if (rx <= radius_clip && ry <= radius_clip) ok = false;
+            if (P.m2x + rx <= 0.f || P.m2x - rx >= (float)W || P.m2y + ry <= 0.f || P.m2y - ry >= (float)H) ok = false;
+        }
+    }
+    if (!ok) {
+        *rad = make_int2(0, 0);
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[0] = z4; rec[1] = z4; rec[2] = z4; rec[3] = z4;
+        return;
+    }
+    float rgb[3];
+    if (color_mode == 0) {
+        // campos = -R^T t ; dir = mean - campos
+        float cp[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) cp[i] = -(cam.R[i] * cam.t[0] + cam.R[3 + i] * cam.t[1] + cam.R[6 + i] * cam.t[2]);
+        float dx = mean[0] - cp[0], dy = mean[1] - cp[1], dz = mean[2] - cp[2];
+        float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+        float b[16];
+        sh_basis(sh_degree, dx * inv, dy * inv, dz * inv, b);
+        const float* c0 = sh0 + 3 * (long long)n;
+        rgb[0] = b[0] * c0[0]; rgb[1] = b[0] * c0[1]; rgb[2] = b[0] * c0[2];
+        int nb = (sh_degree + 1) * (sh_degree + 1);
+        const float* cN = shN + 45 * (long long)n;
+        for (int k = 1; k < nb; k++) {
+            rgb[0] += b[k] * cN[3 * (k - 1)];
+            rgb[1] += b[k] * cN[3 * (k - 1) + 1];
+            rgb[2] += b[k] * cN[3 * (k - 1) + 2];
+        }
+        rgb[0] = fmaxf(rgb[0] + 0.5f, 0.f); rgb[1] = fmaxf(rgb[1] + 0.5f, 0.f); rgb[2] = fmaxf(rgb[2] + 0.5f, 0.f);
+    } else {
+        const float* cc = colors + 3 * (color_mode == 2 ? idx : (long long)n);
+        rgb[0] = cc[0]; rgb[1] = cc[1]; rgb[2] = cc[2];
+    }
+    *rad = make_int2((int)rx, (int)ry);
+    rec[0] = make_float4(P.m2x, P.m2y, P.conA, P.conB);
+    rec[1] = make_float4(P.conC, opa, rgb[0], rgb[1]);
+    rec[2] = make_float4(rgb[2], P.mc[2], P.comp, 0.f);
+    rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// -------------------------------------------------------------------------- backward
+// One thread per Gaussian, loops over cameras; every output is written exactly once.
+// Also accumulates the densify statistics (screen-space gradient norm, visibility count,
+// max screen radius) that gsplat's DefaultStrategy._update_state computes in torch.
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int C, int N, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ sh0, const float* __restrict__ shN, int color_mode, int sh_degree,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, int W, int H, float eps2d, int flags,
+    const int32_t* __restrict__ radii, const float* __restrict__ splats, const float* __restrict__ v_splats,
+    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+    float* __restrict__ v_opacities, float* __restrict__ v_sh0, float* __restrict__ v_shN,
+    float* __restrict__ v_colors,
+    float* __restrict__ stat_grad2d, float* __restrict__ stat_count, float* __restrict__ stat_radii,
+    int stat_use_abs) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+    float sraw[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    float s[3] = {sraw[0], sraw[1], sraw[2]};
+    if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
+    float opa_raw = opacities ? opacities[n] : 1.f;
+    float opa_act = (flags & MI_FLAG_LOGIT_OPAC) ? sigmoidf(opa_raw) : opa_raw;
+    float Rq[9], inv_norm, Sw[9];
+    quat_to_rotmat(q, Rq, inv_norm);
+    covar_world(Rq, s, Sw);
+
+    float vmean[3] = {0.f, 0.f, 0.f};
+    float vSw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float vopa = 0.f;
+    float vc0[3] = {0.f, 0.f, 0.f};
+    float vcN[45];
+    int nb = (sh_degree + 1) * (sh_degree + 1);
+    if (color_mode == 0) {
+#pragma unroll
+        for (int k = 0; k < 45; k++) vcN[k] = 0.f;
+    }
+    float g2d = 0.f, cnt = 0.f, rmax = 0.f;
+
+    for (int c = 0; c < C; c++) {
+        long long idx = (long long)c * N + n;
+        int2 rad = *reinterpret_cast<const int2*>(radii + idx * 2);
+        if (rad.x <= 0 || rad.y <= 0) {
+            if (color_mode == 2 && v_colors) { v_colors[3 * idx] = 0.f; v_colors[3 * idx + 1] = 0.f; v_colors[3 * idx + 2] = 0.f; }
+            continue;
+        }
+        const float4* vr = reinterpret_cast<const float4*>(v_splats + idx * GRAD_STRIDE);
+        float4 g0 = vr[0], g1 = vr[1], g2 = vr[2];
+        float v_m2x = g0.x, v_m2y = g0.y, v_cA = g0.z, v_cB = g0.w, v_cC = g1.x, v_op = g1.y;
+        float v_rgb[3] = {g1.z, g1.w, g2.x};
+        float v_depth = g2.w;
+        // densify statistics
+        {
+            float sx = stat_use_abs ? g2.y : v_m2x, sy = stat_use_abs ? g2.z : v_m2y;
+            sx *= 0.5f * W * C; sy *= 0.5f * H * C;
+            g2d += sqrtf(sx * sx + sy * sy);
+            cnt += 1.f;
+            rmax = fmaxf(rmax, fmaxf((float)rad.x, (float)rad.y) / (float)max(W, H));
+        }
+        Cam cam = load_cam(viewmats, Ks, c);
+        Proj P;
+        project_core(cam, mean, Sw, W, H, eps2d, P);
+
+        // ---- colour path
+        if (color_mode == 0) {
+            const float4* sr = reinterpret_cast<const float4*>(splats + idx * SPLAT_STRIDE);
+            float4 s1 = sr[1], s2 = sr[2];
+            // clamp(+0.5, min 0) mask
+            if (s1.z <= 0.f) v_rgb[0] = 0.f;
+            if (s1.w <= 0.f) v_rgb[1] = 0.f;
+            if (s2.x <= 0.f) v_rgb[2] = 0.f;
+            float cp[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) cp[i] = -(cam.R[i] * cam.t[0] + cam.R[3 + i] * cam.t[1] + cam.R[6 + i] * cam.t[2]);
+            float dx = mean[0] - cp[0], dy = mean[1] - cp[1], dz = mean[2] - cp[2];
+            float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+            float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float b[16], gk[16];
+            sh_basis(sh_degree, ux, uy, uz, b);
+            vc0[0] += b[0] * v_rgb[0]; vc0[1] += b[0] * v_rgb[1]; vc0[2] += b[0] * v_rgb[2];
+            gk[0] = 0.f;
+            const float* cN = shN + 45 * (long long)n;
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                if (k < nb) {
+                    vcN[3 * (k - 1)] += b[k] * v_rgb[0];
+                    vcN[3 * (k - 1) + 1] += b[k] * v_rgb[1];
+                    vcN[3 * (k - 1) + 2] += b[k] * v_rgb[2];
+                    gk[k] = v_rgb[0] * cN[3 * (k - 1)] + v_rgb[1] * cN[3 * (k - 1) + 1] + v_rgb[2] * cN[3 * (k - 1) + 2];
+                } else gk[k] = 0.f;
+            }
+            float vu[3];
+            sh_basis_vjp(sh_degree, ux, uy, uz, gk, vu);
+            // normalisation vjp: v_d = (v_u - (v_u . u) u) / |d|
+            float dot = vu[0] * ux + vu[1] * uy + vu[2] * uz;
+            vmean[0] += (vu[0] - dot * ux) * inv;
+            vmean[1] += (vu[1] - dot * uy) * inv;
+            vmean[2] += (vu[2] - dot * uz) * inv;
+        } else if (v_colors) {
+            if (color_mode == 2) { v_colors[3 * idx] = v_rgb[0]; v_colors[3 * idx + 1] = v_rgb[1]; v_colors[3 * idx + 2] = v_rgb[2]; }
+            else { vc0[0] += v_rgb[0]; vc0[1] += v_rgb[1]; vc0[2] += v_rgb[2]; }
+        }
+
+        // ---- opacity / compensation
+        float vcov_a = 0.f, vcov_b = 0.f, vcov_c = 0.f;   // symmetric 2x2 grad: [[a, b],[b, c]]
+        if (flags & MI_FLAG_ANTIALIASED) {
+            vopa += v_op * P.comp;
+            float v_comp = v_op * opa_act;
+            float det_conic = P.conA * P.conC - P.conB * P.conB;
+            float v_sqr = v_comp * 0.5f / (P.comp + 1e-6f);
+            float om = 1.f - P.comp * P.comp;
+            vcov_a += v_sqr * (om * P.conA - eps2d * det_conic);
+            vcov_b += v_sqr * (om * P.conB);
+            vcov_c += v_sqr * (om * P.conC - eps2d * det_conic);
+        } else {
+            vopa += v_op;
+        }
+        // ---- conic = inverse(cov2d): G_cov = -X G_X X, G_X = [[vA, vB/2],[vB/2, vC]]
+        {
+            float xa = P.conA, xb = P.conB, xc = P.conC;
+            float ga = v_cA, gb = 0.5f * v_cB, gc = v_cC;
+            // T = X G
+            float t00 = xa * ga + xb * gb, t01 = xa * gb + xb * gc;
+            float t10 = xb * ga + xc * gb, t11 = xb * gb + xc * gc;
+            vcov_a -= t00 * xa + t01 * xb;
+            vcov_b -= t00 * xb + t01 * xc;
+            vcov_c -= t10 * xb + t11 * xc;
+        }
+        // ---- cov2d = J Sc J^T ; mean2d
+        float G[4] = {vcov_a, vcov_b, vcov_b, vcov_c};
+        float vSc[9];
+        // v_Sc = J^T G J
+        {
+            float GJ[6];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) GJ[3 * i + j] = G[2 * i] * P.J[j] + G[2 * i + 1] * P.J[3 + j];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) vSc[3 * i + j] = P.J[i] * GJ[j] + P.J[3 + i] * GJ[3 + j];
+            // v_J = 2 G J Sc  (G, Sc symmetric)
+            float vJ[6];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    vJ[3 * i + j] = 2.f * (GJ[3 * i] * P.Sc[j] + GJ[3 * i + 1] * P.Sc[3 + j] + GJ[3 * i + 2] * P.Sc[6 + j]);
+            float x = P.mc[0], y = P.mc[1], z = P.mc[2];
+            float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+            float vmc[3];
+            vmc[0] = cam.fx * rz * v_m2x;
+            vmc[1] = cam.fy * rz * v_m2y;
+            vmc[2] = -(cam.fx * x * v_m2x + cam.fy * y * v_m2y) * rz2 + v_depth;
+            if (P.x_in) vmc[0] += -cam.fx * rz2 * vJ[2];
+            else vmc[2] += -cam.fx * rz3 * vJ[2] * P.tx;
+            if (P.y_in) vmc[1] += -cam.fy * rz2 * vJ[5];
+            else vmc[2] += -cam.fy * rz3 * vJ[5] * P.ty;
+            vmc[2] += -cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4] + 2.f * cam.fx * P.tx * rz3 * vJ[2] +
+                      2.f * cam.fy * P.ty * rz3 * vJ[5];
+            // world: v_mean += R^T v_mc ; v_Sw += R^T v_Sc R
+#pragma unroll
+            for (int i = 0; i < 3; i++) vmean[i] += cam.R[i] * vmc[0] + cam.R[3 + i] * vmc[1] + cam.R[6 + i] * vmc[2];
+            float tmp[9], acc[9];
+            mat3_mul_at(cam.R, vSc, tmp);
+            mat3_mul(tmp, cam.R, acc);
+#pragma unroll
+            for (int i = 0; i < 9; i++) vSw[i] += acc[i];
+        }
+    }
+
+    // ---- Sigma = M M^T, M = R diag(s): v_M = (v_S + v_S^T) M
+    float M[9], vM[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[3 * i + j] = Rq[3 * i + j] * s[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            vM[3 * i + j] = (vSw[3 * i] + vSw[i]) * M[j] + (vSw[3 * i + 1] + vSw[3 + i]) * M[3 + j] +
+                            (vSw[3 * i + 2] + vSw[6 + i]) * M[6 + j];
+    float vs[3], vR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) vs[j] = Rq[j] * vM[j] + Rq[3 + j] * vM[3 + j] + Rq[6 + j] * vM[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) vR[3 * i + j] = vM[3 * i + j] * s[j];
+    float w = q[0] * inv_norm, x = q[1] * inv_norm, y = q[2] * inv_norm, z = q[3] * inv_norm;
+    float vqn[4];
+    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+    float dq = vqn[0] * w + vqn[1] * x + vqn[2] * y + vqn[3] * z;
+    float qn[4] = {w, x, y, z};
+#pragma unroll
+    for (int i = 0; i < 4; i++) v_quats[4 * n + i] = (vqn[i] - dq * qn[i]) * inv_norm;
+    if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
+    v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
+    v_means[3 * n] = vmean[0]; v_means[3 * n + 1] = vmean[1]; v_means[3 * n + 2] = vmean[2];
+    if (v_opacities) {
+        if (flags & MI_FLAG_LOGIT_OPAC) vopa *= opa_act * (1.f - opa_act);
+        v_opacities[n] = vopa;
+    }
+    if (color_mode == 0) {
+        v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
+        float* o = v_shN + 45 * (long long)n;
+#pragma unroll
+        for (int k = 0; k < 45; k++) o[k] = vcN[k];
+    } else if (color_mode == 1 && v_colors) {
+        v_colors[3 * n] = vc0[0]; v_colors[3 * n + 1] = vc0[1]; v_colors[3 * n + 2] = vc0[2];
+    }
+    if (stat_grad2d) {
+        stat_grad2d[n] += g2d;
+        stat_count[n] += cnt;
+        if (stat_radii) stat_radii[n] = fmaxf(stat_radii[n], rmax);
+    }
+}
+
+}  // namespace
+
+extern "C" int mi3dgs_project_fwd(int C, int N, const float* means, const float* quats, const float* scales,
+                                  const float* opacities, const float* sh0, const float* shN,
+                                  const float* colors, int color_mode, int sh_degree, const float* viewmats,
+                                  const float* Ks, int width, int height, float eps2d, float near_plane,
+                                  float far_plane, float radius_clip, int flags, int32_t* radii, float* splats,
+                                  void* stream) {
+    MI_REQUIRE(C > 0 && N >= 0 && width > 0 && height > 0, "project_fwd: bad sizes");
+    MI_REQUIRE(color_mode >= 0 && color_mode <= 2, "project_fwd: color_mode must be 0, 1 or 2");
+    MI_REQUIRE(color_mode != 0 || (sh_degree >= 0 && sh_degree <= 3 && sh0 && (sh_degree == 0 || shN)),
+               "project_fwd: SH mode needs sh0/shN and 0 <= sh_degree <= 3");
+    MI_REQUIRE(color_mode == 0 || colors, "project_fwd: colour mode needs colors");
+    if (N == 0) return 0;
+    long long total = (long long)C * N;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(mi_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
+                       quats, scales, opacities, sh0, shN, colors, color_mode, sh_degree, viewmats, Ks, width, height,
+                       eps2d, near_plane, far_plane, radius_clip, flags, radii, splats);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float* quats, const float* scales,
+                                  const float* opacities, const float* sh0, const float* shN, int color_mode,
+                                  int sh_degree, const float* viewmats, const float* Ks, int width, int height,
+                                  float eps2d, int flags, const int32_t* radii, const float* splats,
+                                  const float* v_splats, float* v_means, float* v_quats, float* v_scales,
+                                  float* v_opacities, float* v_sh0, float* v_shN, float* v_colors,
+                                  float* stat_grad2d, float* stat_count, float* stat_radii, int stat_use_abs,
+                                  void* stream) {
+    MI_REQUIRE(C > 0 && N >= 0, "project_bwd: bad sizes");
+    MI_REQUIRE(v_means && v_quats && v_scales, "project_bwd: v_means/v_quats/v_scales required");
+    MI_REQUIRE(color_mode != 0 || (v_sh0 && v_shN), "project_bwd: SH mode needs v_sh0/v_shN");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
+                       quats, scales, opacities, sh0, shN, color_mode, sh_degree, viewmats, Ks, width, height, eps2d,
+                       flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_colors,
+                       stat_grad2d, stat_count, stat_radii, stat_use_abs);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

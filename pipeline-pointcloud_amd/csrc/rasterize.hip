@@ -1,0 +1,269 @@
+// Tile rasteriser, forward and backward.  gfx950 only.
+//
+// Replaces gsplat rasterize_to_pixels_{fwd,bwd}, reached by the
+// reference only through main.py:1312 / main.py:1343.
+//
+// One 256-thread workgroup per 16x16 tile = 4 wave64s, each wave owning an 8x8 pixel
+// quadrant (tighter screen footprint per wave => more wave-uniform skips than a 16x4 strip).
+// The tile's depth-sorted splat records are gathered 256 at a time, ONE 64-byte line each,
+// into LDS and then read back as broadcasts.
+//
+// Backward: per-pixel replay back-to-front; per-splat partials are reduced across the wave
+// with DPP (no LDS traffic), combined across the 4 waves in an LDS [slot][16] table, and
+// flushed with lanes mapped (record, dword) so that each (tile, Gaussian) costs ONE 64-byte
+// float-atomic request into the packed gradient record (MI355X_MICROARCH "Global float
+// atomics": requests, not bytes, are the unit that is rate-limited).
+//
+// Bound: VALU/LDS (about 20 flop fwd, 60 flop bwd per pixel-splat pair); HBM traffic is
+// I*64 B gather + Px*20 B fwd, I*64 B gather + I*64 B atomics + Px*36 B bwd.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;
+
+__device__ __forceinline__ void pixel_of_thread(int tid, int& lx, int& ly) {
+    int w = tid >> 6, l = tid & 63;
+    lx = ((w & 1) << 3) + (l & 7);
+    ly = ((w >> 1) << 3) + (l >> 3);
+}
+
+template <bool HAS_BG>
+__global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
+    int32_t* __restrict__ last_ids) {
+    __shared__ float4 sA[BLOCK], sB[BLOCK];
+    __shared__ float sC[BLOCK];
+    int t = blockIdx.x;
+    int cam = t / (tw * th);
+    int tile_in = t - cam * (tw * th);
+    int ty = tile_in / tw, tx = tile_in - ty * tw;
+    int lx, ly;
+    pixel_of_thread(threadIdx.x, lx, ly);
+    int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
+    bool inside = px_i < W && py_i < H;
+    float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    int start = tile_offsets[t];
+    int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+
+    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    int cur = 0;
+    bool done = !inside;
+    for (int bs = start; bs < end; bs += BLOCK) {
+        if (__syncthreads_count(done) == BLOCK) break;
+        int idx = bs + (int)threadIdx.x;
+        if (idx < end) {
+            const float4* rec = reinterpret_cast<const float4*>(splats + (size_t)flatten_ids[idx] * SPLAT_STRIDE);
+            float4 a = rec[0], bb = rec[1];
+            float c = reinterpret_cast<const float*>(rec)[SP_B];
+            sA[threadIdx.x] = a; sB[threadIdx.x] = bb; sC[threadIdx.x] = c;
+        }
+        __syncthreads();
+        int bsz = min(BLOCK, end - bs);
+        if (!done) {
+            for (int k = 0; k < bsz; k++) {
+                float4 a = sA[k], bb = sB[k];
+                float dx = a.x - px, dy = a.y - py;
+                float sigma = 0.5f * (a.z * dx * dx + bb.x * dy * dy) + a.w * dx * dy;
+                float alpha = fminf(MAX_ALPHA, bb.y * __expf(-sigma));
+                if (sigma < 0.f || alpha < ALPHA_THRESHOLD) continue;
+                float nT = T * (1.f - alpha);
+                if (nT <= T_STOP) { done = true; break; }
+                float wgt = alpha * T;
+                r += bb.z * wgt; g += bb.w * wgt; b += sC[k] * wgt;
+                cur = bs + k;
+                T = nT;
+            }
+        }
+    }
+    if (inside) {
+        size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        if (HAS_BG) {
+            const float* bg = backgrounds + 3 * cam;
+            r += T * bg[0]; g += T * bg[1]; b += T * bg[2];
+        }
+        render[3 * pix] = r; render[3 * pix + 1] = g; render[3 * pix + 2] = b;
+        alphas[pix] = 1.f - T;
+        last_ids[pix] = cur;
+    }
+}
+
+template <bool HAS_BG, bool ABSGRAD>
+__global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
+    __shared__ float4 sA[BLOCK], sB[BLOCK];
+    __shared__ float sC[BLOCK];
+    __shared__ int sId[BLOCK];
+    __shared__ float acc[BLOCK][GRAD_STRIDE];
+    __shared__ int touched[BLOCK];
+    __shared__ int wave_max[4];
+
+    int t = blockIdx.x;
+    int cam = t / (tw * th);
+    int tile_in = t - cam * (tw * th);
+    int ty = tile_in / tw, tx = tile_in - ty * tw;
+    int lx, ly;
+    pixel_of_thread(threadIdx.x, lx, ly);
+    int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
+    bool inside = px_i < W && py_i < H;
+    float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    int start = tile_offsets[t];
+    int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+    if (end <= start) return;
+    int lane = lane_id(), wv = threadIdx.x >> 6;
+
+    float T_final = 1.f, vr0 = 0.f, vr1 = 0.f, vr2 = 0.f, va = 0.f;
+    int bin_final = -1;
+    if (inside) {
+        size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        T_final = 1.f - alphas[pix];
+        bin_final = last_ids[pix];
+        vr0 = v_render[3 * pix]; vr1 = v_render[3 * pix + 1]; vr2 = v_render[3 * pix + 2];
+        va = v_alphas[pix];
+        // a pixel that composited nothing has last_id 0 and alpha 0: replaying splat `start`
+        // is then harmless only if it is skipped, so mark it explicitly
+        if (alphas[pix] == 0.f) bin_final = -1;
+    }
+    float bgdot = 0.f;
+    if (HAS_BG) {
+        const float* bg = backgrounds + 3 * cam;
+        bgdot = bg[0] * vr0 + bg[1] * vr1 + bg[2] * vr2;
+    }
+    // wave / block maximum of bin_final
+    int wmax = bin_final;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0) wave_max[wv] = wmax;
+    __syncthreads();
+    int bmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (bmax < start) return;
+
+    float T = T_final;
+    float buf0 = 0.f, buf1 = 0.f, buf2 = 0.f;
+    for (int be = bmax; be >= start; be -= BLOCK) {
+        // slot k <-> sorted index be - k
+        int idx = be - (int)threadIdx.x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GRAD_STRIDE; k++) acc[threadIdx.x][k] = 0.f;
+        touched[threadIdx.x] = 0;
+        if (idx >= start) {
+            int id = flatten_ids[idx];
+            const float4* rec = reinterpret_cast<const float4*>(splats + (size_t)id * SPLAT_STRIDE);
+            sA[threadIdx.x] = rec[0]; sB[threadIdx.x] = rec[1];
+            sC[threadIdx.x] = reinterpret_cast<const float*>(rec)[SP_B];
+            sId[threadIdx.x] = id;
+        }
+        __syncthreads();
+        int bsz = min(BLOCK, be - start + 1);
+        int k0 = max(0, be - wmax);          // wave-uniform: nothing in this wave is live before k0
+        for (int k = k0; k < bsz; k++) {
+            int sidx = be - k;
+            float4 a = sA[k], bb = sB[k];
+            float cb = sC[k];
+            float dx = a.x - px, dy = a.y - py;
+            float sigma = 0.5f * (a.z * dx * dx + bb.x * dy * dy) + a.w * dx * dy;
+            float vis = __expf(-sigma);
+            float alpha = fminf(MAX_ALPHA, bb.y * vis);
+            bool valid = (sidx <= bin_final) && !(sigma < 0.f || alpha < ALPHA_THRESHOLD);
+            if (__ballot(valid) == 0ull) continue;
+            float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+            float g_ax = 0.f, g_ay = 0.f;
+            if (valid) {
+                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                T *= ra;
+                float fac = alpha * T;
+                g_r = fac * vr0; g_g = fac * vr1; g_b = fac * vr2;
+                float v_alpha = (bb.z * T - buf0 * ra) * vr0 + (bb.w * T - buf1 * ra) * vr1 + (cb * T - buf2 * ra) * vr2;
+                v_alpha += T_final * ra * va;
+                if (HAS_BG) v_alpha -= T_final * ra * bgdot;
+                buf0 += bb.z * fac; buf1 += bb.w * fac; buf2 += cb * fac;
+                if (bb.y * vis <= MAX_ALPHA) {
+                    float v_sigma = -bb.y * vis * v_alpha;
+                    g_ca = 0.5f * v_sigma * dx * dx;
+                    g_cb = v_sigma * dx * dy;
+                    g_cc = 0.5f * v_sigma * dy * dy;
+                    g_x = v_sigma * (a.z * dx + a.w * dy);
+                    g_y = v_sigma * (a.w * dx + bb.x * dy);
+                    g_o = vis * v_alpha;
+                    if (ABSGRAD) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
+                }
+            }
+            g_x = wave_sum_to_lane63(g_x); g_y = wave_sum_to_lane63(g_y);
+            g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+            g_o = wave_sum_to_lane63(g_o);
+            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+            if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
+            if (lane == 63) {
+                float* o = acc[k];
+                atomicAdd(&o[GR_X], g_x); atomicAdd(&o[GR_Y], g_y);
+                atomicAdd(&o[GR_CA], g_ca); atomicAdd(&o[GR_CB], g_cb); atomicAdd(&o[GR_CC], g_cc);
+                atomicAdd(&o[GR_OPA], g_o);
+                atomicAdd(&o[GR_R], g_r); atomicAdd(&o[GR_G], g_g); atomicAdd(&o[GR_B], g_b);
+                if (ABSGRAD) { atomicAdd(&o[GR_ABSX], g_ax); atomicAdd(&o[GR_ABSY], g_ay); }
+                touched[k] = 1;
+            }
+        }
+        __syncthreads();
+        // flush: lane -> (record = lane>>4, dword = lane&15): 4 records = 4 x 64-B requests per instruction
+        for (int s = wv * 64; s < wv * 64 + 64; s += 4) {
+            int slot = s + (lane >> 4);
+            int comp = lane & 15;
+            if (slot < bsz && touched[slot] && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
+                float v = acc[slot][comp];
+                atomicAdd(&v_splats[(size_t)sId[slot] * GRAD_STRIDE + comp], v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
+                                    const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                    const int32_t* n_isect_dev, const float* backgrounds, float* render,
+                                    float* alphas, int32_t* last_ids, void* stream) {
+    MI_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size must be 16");
+    MI_REQUIRE(C > 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
+    MI_REQUIRE(tile_width == mi_div_up(width, TILE) && tile_height == mi_div_up(height, TILE),
+               "rasterize_fwd: tile grid does not match image size");
+    int n_tiles = C * tile_width * tile_height;
+    hipStream_t st = (hipStream_t)stream;
+    if (backgrounds)
+        hipLaunchKernelGGL(rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                           tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
+                           alphas, last_ids);
+    else
+        hipLaunchKernelGGL(rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                           tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
+                           alphas, last_ids);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
+                                    const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                    const int32_t* n_isect_dev, const float* backgrounds, const float* alphas,
+                                    const int32_t* last_ids, const float* v_render, const float* v_alphas,
+                                    int absgrad, float* v_splats, void* stream) {
+    MI_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size must be 16");
+    MI_REQUIRE(tile_width == mi_div_up(width, TILE) && tile_height == mi_div_up(height, TILE),
+               "rasterize_bwd: tile grid does not match image size");
+    int n_tiles = C * tile_width * tile_height;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BWD(BG, AG)                                                                                            \
+    hipLaunchKernelGGL((rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,   \
+                       tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas,     \
+                       last_ids, v_render, v_alphas, v_splats)
+    if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
+    else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+#undef LAUNCH_BWD
+    MI_LAUNCH_CHECK();
+    return 0;
+}

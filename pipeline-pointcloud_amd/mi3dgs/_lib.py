@@ -1,0 +1,87 @@
+"""ctypes binding of libmi3dgs.so (the C-ABI declared in include/mi3dgs.h).
+
+There is NO fallback: if the HIP library is missing or a call fails this module raises.
+The product path never imports anything from `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi3dgs.so")
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+
+_lib: Optional[C.CDLL] = None
+
+_f = C.c_void_p      # device pointers travel as void*
+_i = C.c_int
+_ll = C.c_longlong
+_fl = C.c_float
+_sz = C.c_size_t
+_u32 = C.c_uint32
+
+_SIGNATURES = {
+    "mi3dgs_last_error": (C.c_char_p, []),
+    "mi3dgs_abi_version": (_i, []),
+    "mi3dgs_splat_stride": (_i, []),
+    "mi3dgs_grad_stride": (_i, []),
+    "mi3dgs_project_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _i,
+                                _f, _f, _f]),
+    "mi3dgs_project_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
+                                _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
+    "mi3dgs_bin_workspace_bytes": (_sz, [_i, _i, _ll]),
+    "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
+    "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),
+    "mi3dgs_sort_workspace_bytes": (_sz, [_ll]),
+    "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
+    "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),
+    "mi3dgs_scan_exclusive_u32": (_i, [_f, _f, _ll, _f, _f, _sz, _f]),
+    "mi3dgs_rasterize_fwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
+    "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
+    "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
+    "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
+    "mi3dgs_scale_reg": (_i, [_i, _f, _fl, _fl, _f, _f, _f]),
+    "mi3dgs_adam_step": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_ll),
+                              C.POINTER(_fl), _i, _fl, _fl, _fl, _f]),
+    "mi3dgs_densify_decide": (_i, [_i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f]),
+    "mi3dgs_densify_scatter": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
+                                    C.POINTER(_f), _f, _f, _ll, _u32, _f]),
+    "mi3dgs_reset_opacity": (_i, [_i, _f, _fl, _f, _f, _f]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+class Mi3dgsError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the library (once).  Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise Mi3dgsError(
+                f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` "
+                "(or __graft_entry__.build()).  mi3dgs has no fallback path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)     # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if handle.mi3dgs_abi_version() != 1:
+            raise Mi3dgsError("libmi3dgs.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().mi3dgs_last_error()
+        raise Mi3dgsError(msg.decode() if msg else f"mi3dgs call failed with code {rc}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args))

@@ -1,0 +1,260 @@
+"""3DGS training loop over the mi3dgs C-ABI: the work `Train-Stage1` does in the reference.
+
+Mirrors what the reference launches as a subprocess --
+  source/container/src/main.py:1270-1316  `ns-train splatfacto ...`        (single GPU)
+  source/container/src/main.py:1318-1347  `simple_trainer.py default ...`  (multi GPU)
+-- with upstream gsplat `simple_trainer.py` / DefaultStrategy defaults (SURVEY.md
+Appendix A; [UPSTREAM-UNVERIFIED], the reference passes almost no hyper-parameters).
+
+No autograd in the loop: forward, loss, backward, Adam and densify are explicit calls into
+pre-allocated buffers, so one iteration is a fixed sequence of kernel launches on one stream.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+GROUPS = ("means", "quats", "scales", "opacities", "sh0", "shN")
+WIDTHS = (3, 4, 3, 1, 3, 45)
+_SHAPES = {"means": (3,), "quats": (4,), "scales": (3,), "opacities": (), "sh0": (1, 3), "shN": (15, 3)}
+
+
+@dataclass
+class TrainConfig:
+    max_steps: int = 30_000
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    ssim_lambda: float = 0.2
+    # Adam (gsplat simple_trainer defaults; means lr is multiplied by scene_scale and decays to 1%)
+    lr_means: float = 1.6e-4
+    lr_means_final_ratio: float = 0.01
+    lr_scales: float = 5e-3
+    lr_quats: float = 1e-3
+    lr_opacities: float = 5e-2
+    lr_sh0: float = 2.5e-3
+    lr_shN: float = 2.5e-3 / 20
+    adam_eps: float = 1e-15
+    scene_scale: float = 1.0
+    # DefaultStrategy
+    densify: bool = True
+    prune_opa: float = 0.005
+    grow_grad2d: float = 0.0002
+    grow_scale3d: float = 0.01
+    prune_scale3d: float = 0.1
+    refine_start_iter: int = 500
+    refine_stop_iter: int = 15_000
+    reset_every: int = 3000
+    refine_every: int = 100
+    pause_refine_after_reset: int = 0
+    absgrad: bool = False
+    # splatfacto extras the reference turns on (main.py:1288)
+    use_scale_regularization: bool = False
+    scale_reg_weight: float = 0.1
+    max_gauss_ratio: float = 10.0
+    scale_reg_every: int = 10
+    random_background: bool = False
+    antialiased: bool = False
+    near_plane: float = 0.01
+    far_plane: float = 1e10
+    # capacities: Gaussians (densify target buffers) and tile intersections (None = read the
+    # count back every step and allocate exactly; an int = no host sync in the step)
+    capacity: Optional[int] = None
+    max_isect: Optional[int] = None
+    seed: int = 0
+
+
+class GaussianModel:
+    """Parameter + Adam-moment store with spare capacity and two banks (densify ping-pong)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None):
+        dev = params["means"].device
+        self.device = dev
+        self.n = int(params["means"].shape[0])
+        self.capacity = int(capacity or self.n)
+        if self.capacity < self.n:
+            raise ValueError("capacity smaller than the initial number of Gaussians")
+        self.banks = []
+        for b in range(2):
+            bank = {}
+            for g, w in zip(GROUPS, WIDTHS):
+                bank[g] = {k: torch.zeros(self.capacity, w, dtype=torch.float32, device=dev) for k in ("p", "m", "v")}
+            self.banks.append(bank)
+        self.cur = 0
+        for g, w in zip(GROUPS, WIDTHS):
+            self.banks[0][g]["p"][: self.n] = params[g].reshape(self.n, w).to(torch.float32)
+        self.grads = {g: torch.zeros(self.capacity, w, dtype=torch.float32, device=dev) for g, w in zip(GROUPS, WIDTHS)}
+
+    def _view(self, t: torch.Tensor, g: str) -> torch.Tensor:
+        return t[: self.n].view((self.n,) + _SHAPES[g])
+
+    def p(self, g: str) -> torch.Tensor:
+        return self._view(self.banks[self.cur][g]["p"], g)
+
+    def grad(self, g: str) -> torch.Tensor:
+        return self._view(self.grads[g], g)
+
+    def state(self, g: str, k: str) -> torch.Tensor:
+        return self.banks[self.cur][g][k][: self.n]
+
+    def splats_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The checkpoint schema the reference's exporter reads (gsplat_pt_to_ply.py:45-73)."""
+        return {g: self.p(g).detach().clone() for g in GROUPS}
+
+
+class Trainer:
+    def __init__(self, params: Dict[str, torch.Tensor], viewmats: torch.Tensor, Ks: torch.Tensor,
+                 images: torch.Tensor, width: int, height: int, cfg: Optional[TrainConfig] = None):
+        self.cfg = cfg or TrainConfig()
+        self.model = GaussianModel(params, self.cfg.capacity)
+        dev = self.model.device
+        self.device = dev
+        self.viewmats, self.Ks = viewmats.to(dev).contiguous(), Ks.to(dev).contiguous()
+        self.images = images          # [V,H,W,3] float32 in [0,1] on the device
+        self.W, self.H = int(width), int(height)
+        self.step_count = 0
+        cap = self.model.capacity
+        self.radii = torch.empty(1, cap, 2, dtype=torch.int32, device=dev)
+        self.splats = torch.empty(1, cap, ops.SPLAT_STRIDE, dtype=torch.float32, device=dev)
+        self.v_splats = torch.zeros(1, cap, ops.GRAD_STRIDE, dtype=torch.float32, device=dev)
+        self.raster_out: Dict = {}
+        self.loss_scratch: Dict = {}
+        self.v_render = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
+        self.v_alphas = torch.zeros(1, self.H, self.W, 1, dtype=torch.float32, device=dev)
+        self.stats = {k: torch.zeros(cap, dtype=torch.float32, device=dev) for k in ("grad2d", "count", "radii")}
+        self.flags_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        self.count_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.offs_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.total_buf = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
+        self.last: Dict = {}
+
+    # -- helpers -------------------------------------------------------------------
+    def _n(self) -> int:
+        return self.model.n
+
+    def _flags(self) -> int:
+        f = ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC
+        if self.cfg.antialiased:
+            f |= ops.FLAG_ANTIALIASED
+        return f
+
+    def sh_degree_now(self) -> int:
+        return min(self.step_count // self.cfg.sh_degree_interval, self.cfg.sh_degree)
+
+    def lrs(self):
+        c = self.cfg
+        t = min(self.step_count / max(c.max_steps, 1), 1.0)
+        lr_means = c.lr_means * c.scene_scale * (c.lr_means_final_ratio ** t)
+        return (lr_means, c.lr_quats, c.lr_scales, c.lr_opacities, c.lr_sh0, c.lr_shN)
+
+    def _forward(self, viewmat, K, sh_degree, background=None):
+        m, n = self.model, self._n()
+        radii, splats = self.radii[:, :n], self.splats[:, :n]
+        ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
+                        sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
+                        far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats)
+        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect)
+        render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
+        return radii, splats, binning, render, alphas, last_ids
+
+    @torch.no_grad()
+    def render(self, viewmat: torch.Tensor, K: torch.Tensor, sh_degree: Optional[int] = None, background=None):
+        """Render one view: [1,H,W,3], [1,H,W,1].  (Outputs alias internal buffers.)"""
+        sd = self.cfg.sh_degree if sh_degree is None else sh_degree
+        _, _, _, render, alphas, _ = self._forward(viewmat.view(1, 4, 4), K.view(1, 3, 3), sd, background)
+        return render, alphas
+
+    # -- one training iteration ------------------------------------------------------
+    @torch.no_grad()
+    def step(self, view_index: int, want_loss: bool = False):
+        c, m = self.cfg, self.model
+        n = self._n()
+        viewmat = self.viewmats[view_index: view_index + 1]
+        K = self.Ks[view_index: view_index + 1]
+        gt = self.images[view_index: view_index + 1]
+        sd = self.sh_degree_now()
+        bg = None
+        if c.random_background:
+            bg = torch.rand(1, 3, generator=self.gen).to(self.device)
+        radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg)
+        sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch)
+        ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
+        v_splats = self.v_splats[:, :n]
+        v_splats.zero_()
+        ops.rasterize_bwd(splats, binning, self.W, self.H, alphas, last_ids, self.v_render, self.v_alphas, 16, bg,
+                          c.absgrad, v_splats)
+        grads = {"v_" + g: m.grad(g) for g in GROUPS}
+        track = c.densify and self.step_count < c.refine_stop_iter
+        stats = {k: v[:n] for k, v in self.stats.items()} if track else None
+        ops.project_bwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
+                        radii, splats, v_splats, sh0=m.p("sh0"), shN=m.p("shN"), color_mode=ops.COLOR_SH,
+                        sh_degree=sd, flags=self._flags(), out=grads, stats=stats, stat_use_abs=c.absgrad)
+        if c.use_scale_regularization and self.step_count % c.scale_reg_every == 0:
+            ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
+        self._all_reduce_grads()
+        ops.adam_step([m.banks[m.cur][g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS],
+                      [m.banks[m.cur][g]["m"] for g in GROUPS], [m.banks[m.cur][g]["v"] for g in GROUPS],
+                      self.lrs(), self.step_count + 1, eps=c.adam_eps, numel=[n * w for w in WIDTHS])
+        if c.densify:
+            self._strategy_post_step()
+        self.last = dict(binning=binning, sums=sums)
+        self.step_count += 1
+        if want_loss:
+            return float(ops.loss_value(sums, self.H * self.W * 3, c.ssim_lambda))
+        return None
+
+    def _all_reduce_grads(self):
+        """Hook for the replicated-Gaussian data-parallel mode (parallel.py); no-op on one GPU."""
+        return
+
+    # -- DefaultStrategy.step_post_backward --------------------------------------------
+    def _strategy_post_step(self):
+        c, step = self.cfg, self.step_count
+        if step >= c.refine_stop_iter:
+            return
+        if step > c.refine_start_iter and step % c.refine_every == 0 and step % c.reset_every >= c.pause_refine_after_reset:
+            self.refine(do_grow=True)
+        if step % c.reset_every == 0 and step > 0:
+            self.reset_opacity()
+
+    def refine(self, do_grow: bool = True) -> Dict[str, int]:
+        """One densify+prune pass; returns counts.  One host sync (the new Gaussian count)."""
+        c, m = self.cfg, self.model
+        n = m.n
+        st = ops._stream(self.device)
+        flags, counts, offs = self.flags_buf[:n], self.count_buf[:n], self.offs_buf[:n]
+        ops._lib.call("mi3dgs_densify_decide", n, ops._p(m.p("scales")), ops._p(m.p("opacities")),
+                      ops._p(self.stats["grad2d"]), ops._p(self.stats["count"]), float(c.grow_grad2d),
+                      float(c.grow_scale3d * c.scene_scale), float(c.prune_opa), float(c.prune_scale3d * c.scene_scale),
+                      int(do_grow), int(self.step_count > c.reset_every), ops._p(flags), ops._p(counts), st)
+        ops.scan_exclusive_u32(counts, offs, self.total_buf)
+        new_n = int(self.total_buf.item())
+        if new_n > m.capacity:
+            raise RuntimeError(f"densify would create {new_n} Gaussians but capacity is {m.capacity}; "
+                               "raise TrainConfig.capacity")
+        src, dst = m.banks[m.cur], m.banks[1 - m.cur]
+        seed = (self.cfg.seed * 1000003 + self.step_count * 7919 + 12345) & 0xFFFFFFFF
+        ops._lib.call("mi3dgs_densify_scatter", n,
+                      ops._ptr_array([src[g]["p"] for g in GROUPS]), ops._ptr_array([src[g]["m"] for g in GROUPS]),
+                      ops._ptr_array([src[g]["v"] for g in GROUPS]), ops._ptr_array([dst[g]["p"] for g in GROUPS]),
+                      ops._ptr_array([dst[g]["m"] for g in GROUPS]), ops._ptr_array([dst[g]["v"] for g in GROUPS]),
+                      ops._p(flags), ops._p(offs), m.capacity, seed, st)
+        fl = flags.to(torch.int32)
+        info = dict(n_before=n, n_after=new_n, n_dup=int(((fl & 1) != 0).logical_and((fl & 4) == 0).sum()),
+                    n_split=int(((fl & 2) != 0).logical_and((fl & 4) == 0).sum()), n_prune=int(((fl & 4) != 0).sum()))
+        m.cur = 1 - m.cur
+        m.n = new_n
+        for v in self.stats.values():
+            v.zero_()
+        return info
+
+    def reset_opacity(self):
+        c, m = self.cfg, self.model
+        thr = 2.0 * c.prune_opa
+        ops._lib.call("mi3dgs_reset_opacity", m.n, ops._p(m.p("opacities")), float(math.log(thr / (1.0 - thr))),
+                      ops._p(m.state("opacities", "m")), ops._p(m.state("opacities", "v")), ops._stream(self.device))

@@ -1,0 +1,87 @@
+"""No-GPU checks of the drop-in boundary: the library loads, exports every symbol that
+include/mi3dgs.h declares (and nothing the header does not know), and the host wrappers
+refuse CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi3dgs.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi3dgs_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from mi3dgs import _lib
+    return _lib
+
+
+def test_header_and_binding_agree(built):
+    assert _declared() == list(built.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (mi3dgs_[a-z0-9_]+)", out)))
+    assert exported == _declared()
+    h = ctypes.CDLL(built.LIB_PATH)
+    for name in _declared():
+        assert hasattr(h, name)
+    assert built.lib().mi3dgs_abi_version() == 1
+    assert built.lib().mi3dgs_splat_stride() == 16 and built.lib().mi3dgs_grad_stride() == 16
+
+
+def test_workspace_queries_are_host_only(built):
+    lib = built.lib()
+    a = lib.mi3dgs_bin_workspace_bytes(1, 1000, 0)
+    b = lib.mi3dgs_bin_workspace_bytes(1, 1000, 100000)
+    assert 0 < a < b
+    assert lib.mi3dgs_sort_workspace_bytes(10) > 0 and lib.mi3dgs_scan_workspace_bytes(10) > 0
+
+
+def test_code_object_is_gfx950_only(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={built.LIB_PATH}"],
+                         capture_output=True, text=True)
+    blob = open(built.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_80"):
+        assert other not in blob
+
+
+def test_no_cpu_fallback():
+    from mi3dgs import ops
+    m = torch.zeros(4, 3)
+    with pytest.raises(ValueError, match="GPU"):
+        ops.project_fwd(m, torch.zeros(4, 4), m, torch.zeros(4), torch.eye(4)[None], torch.eye(3)[None], 8, 8,
+                        sh0=torch.zeros(4, 1, 3), shN=torch.zeros(4, 15, 3))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pipeline-pointcloud_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_rasterization_rejects_unsupported_options():
+    import mi3dgs
+    z = torch.zeros(2, 3)
+    with pytest.raises(NotImplementedError):
+        mi3dgs.rasterization(z, torch.zeros(2, 4), z, torch.zeros(2), z, torch.eye(4)[None], torch.eye(3)[None], 8, 8,
+                             render_mode="RGB+D")
+    with pytest.raises(ValueError):
+        mi3dgs.rasterization(z, torch.zeros(2, 4), z, torch.zeros(2), z, torch.eye(4)[None], torch.eye(3)[None], 8, 8,
+                             rasterize_mode="nope")

@@ -1,0 +1,337 @@
+"""GPU parity: every stage of the HIP path, called through the C-ABI, against the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import activated, rel_err, small_scene
+from oracle import gs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from mi3dgs import ops
+    return ops
+
+
+# ----------------------------------------------------------------- scan / sort (bit exact)
+@pytest.mark.parametrize("n", [1, 63, 4096, 4097, 100_003, 2_000_001])
+def test_scan_exclusive_bit_exact(dev, n):
+    ops = _ops()
+    x = torch.randint(0, 50, (n,), dtype=torch.int32)
+    out = ops.scan_exclusive_u32(x.to(dev))
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.scan_exclusive_u32(x.to(dev), total=total)
+    ref = np.concatenate([[0], np.cumsum(x.numpy().astype(np.int64))[:-1]])
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), ref)
+    assert int(total.item()) == int(x.sum())
+
+
+@pytest.mark.parametrize("n,nbits", [(1, 32), (64, 32), (4096, 32), (5000, 13), (100_003, 32), (1_500_000, 13),
+                                     (300_000, 7)])
+def test_radix_sort_stable_bit_exact(dev, n, nbits):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    hi = (1 << nbits) - 1
+    # many duplicates so that stability is exercised
+    keys = torch.randint(0, min(hi, 5000) + 1, (n,), generator=g, dtype=torch.int64)
+    if nbits == 32:
+        keys = keys * 858_993            # spread over the high bits
+    vals = torch.arange(n, dtype=torch.int32)
+    k = keys.to(torch.int32).to(dev) if nbits < 32 else (keys & 0xFFFFFFFF).to(torch.int64).to(torch.int32).to(dev)
+    v = vals.to(dev)
+    ops.sort_pairs_u32(k, v, nbits)
+    order = np.argsort(keys.numpy(), kind="stable")
+    assert np.array_equal(v.cpu().numpy(), vals.numpy()[order])
+    assert np.array_equal(k.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys.numpy()[order])
+
+
+# ------------------------------------------------------------------------- projection + SH
+@pytest.mark.parametrize("sh_degree", [0, 1, 2, 3])
+def test_project_fwd_matches_oracle(dev, sh_degree):
+    ops = _ops()
+    sc = small_scene(n=600, seed=3)
+    sc.params["means"][:40] *= 6.0          # some behind the cameras / outside the frustum
+    sc.params["opacities"][40:60] = -7.0    # some below the 1/255 opacity cut
+    A = activated(sc.params)
+    radii_r, m2d_r, dep_r, con_r, _ = O.projection(A["means"], A["quats"], A["scales"], sc.viewmats.double(),
+                                                   sc.Ks.double(), sc.width, sc.height, opacities=A["opacities"])
+    g = sc.to(dev)
+    radii, splats = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                                    g.viewmats, g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"],
+                                    sh_degree=sh_degree, flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC)
+    radii, splats = radii.cpu(), splats.cpu()
+    vis_r = (radii_r > 0).all(-1)
+    vis = (radii > 0).all(-1)
+    # cull decisions and integer radii: allow rounding flips on a vanishing fraction only
+    assert (vis != vis_r).float().mean() < 2e-3
+    both = vis & vis_r
+    assert both.sum() > 200
+    assert ((radii != radii_r).any(-1) & both).float().mean() < 5e-3
+    assert torch.allclose(splats[..., 0:2][both].double(), m2d_r[both], rtol=1e-4, atol=2e-3)
+    assert torch.allclose(splats[..., 9][both].double(), dep_r[both], rtol=1e-5, atol=1e-5)
+    assert rel_err(splats[..., 2:5][both], con_r[both]) < 1e-4
+    assert torch.allclose(splats[..., 5][both].double(), A["opacities"][None].expand_as(vis)[both], rtol=1e-5, atol=1e-6)
+    campos = torch.linalg.inv(sc.viewmats.double())[:, :3, 3]
+    dirs = A["means"][None] - campos[:, None]
+    cols = torch.clamp(O.spherical_harmonics(sh_degree, dirs, A["sh"][None].expand(len(campos), -1, -1, -1)) + 0.5, min=0)
+    assert torch.allclose(splats[..., 6:9][both].double(), cols[both], rtol=1e-4, atol=1e-5)
+    # culled records are zero
+    assert float(splats[~vis].abs().sum()) == 0
+
+
+def test_project_fwd_plain_colors_and_activated_inputs(dev):
+    ops = _ops()
+    sc = small_scene(n=300, seed=4)
+    A = activated(sc.params, torch.float32)
+    cols = torch.rand(300, 3)
+    radii, splats = ops.project_fwd(A["means"].to(dev), A["quats"].to(dev), A["scales"].to(dev).contiguous(),
+                                    A["opacities"].to(dev).contiguous(), sc.viewmats.to(dev), sc.Ks.to(dev), sc.width,
+                                    sc.height, colors=cols.to(dev))
+    vis = (radii > 0).all(-1).cpu()
+    assert torch.equal(splats[..., 6:9].cpu()[vis], cols[None].expand(2, -1, -1)[vis])
+
+
+# ------------------------------------------------------------------------- tile binning
+@pytest.mark.parametrize("big,n_views", [(False, 1), (True, 2), (True, 3)])
+def test_binning_bit_exact_vs_oracle(dev, big, n_views):
+    ops = _ops()
+    sc = small_scene(n=700, seed=5, big=big, n_views=n_views, width=80, height=56)
+    g = sc.to(dev)
+    radii, splats = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                                    g.viewmats, g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"],
+                                    sh_degree=3, flags=3)
+    b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, want_isect_ids=True, want_tiles_per_gauss=True)
+    # oracle binning on the HIP stage's own outputs => integer work must match bit for bit
+    sp = splats.cpu()
+    tpg, ids, flat = O.isect_tiles(sp[..., 0:2], radii.cpu(), sp[..., 9], 16, b["tile_width"], b["tile_height"])
+    offs = O.isect_offset_encode(ids, n_views, b["tile_width"], b["tile_height"])
+    assert int(b["n_isect"].item()) == ids.numel() > 0
+    assert torch.equal(b["tiles_per_gauss"].cpu(), tpg)
+    assert torch.equal(b["flatten_ids"].cpu(), flat)
+    assert torch.equal(b["isect_ids"].cpu(), ids)
+    assert torch.equal(b["isect_offsets"].cpu(), offs)
+    # capacity mode (no host sync) gives the same live prefix
+    cap = ids.numel() + 1000
+    b2 = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=cap)
+    assert torch.equal(b2["flatten_ids"][: ids.numel()].cpu(), flat)
+    assert torch.equal(b2["isect_offsets"].cpu(), offs)
+
+
+def test_binning_empty_scene(dev):
+    ops = _ops()
+    sc = small_scene(n=50, seed=6)
+    g = sc.to(dev)
+    far = g.params["means"] + 1000.0          # everything behind / outside
+    radii, splats = ops.project_fwd(far, g.params["quats"], g.params["scales"], g.params["opacities"], g.viewmats,
+                                    g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"], sh_degree=3,
+                                    flags=3)
+    assert int((radii > 0).sum()) == 0
+    b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16)
+    assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
+    bg = torch.rand(2, 3, device=dev)
+    r, a, _ = ops.rasterize_fwd(splats, b, sc.width, sc.height, 16, bg)
+    assert torch.equal(r, bg[:, None, None, :].expand_as(r)) and float(a.abs().max()) == 0
+
+
+# -------------------------------------------------------------------- full forward/backward
+def _run_both(sc, dev, sh_degree=3, bg=True, mode="classic", absgrad=False):
+    import mi3dgs
+    A = activated(sc.params)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in A.items()}
+    C = sc.viewmats.shape[0]
+    bgs = torch.rand(C, 3, generator=torch.Generator().manual_seed(1)).double() if bg else None
+    r_ref, a_ref, meta_ref = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"],
+                                             leaves["sh"], sc.viewmats.double(), sc.Ks.double(), sc.width, sc.height,
+                                             sh_degree=sh_degree, backgrounds=bgs, rasterize_mode=mode)
+    gl = {k: v.detach().float().to(dev).requires_grad_(True) for k, v in A.items()}
+    r, a, meta = mi3dgs.rasterization(gl["means"], gl["quats"], gl["scales"], gl["opacities"], gl["sh"],
+                                      sc.viewmats.to(dev), sc.Ks.to(dev), sc.width, sc.height, sh_degree=sh_degree,
+                                      backgrounds=None if bgs is None else bgs.float().to(dev), rasterize_mode=mode,
+                                      absgrad=absgrad)
+    return (r_ref, a_ref, meta_ref, leaves), (r, a, meta, gl)
+
+
+@pytest.mark.parametrize("mode,bg,sh_degree", [("classic", True, 3), ("classic", False, 1), ("antialiased", True, 2)])
+def test_rasterization_forward_matches_oracle(dev, mode, bg, sh_degree):
+    sc = small_scene(n=500, seed=7, big=True, width=72, height=40)
+    (r_ref, a_ref, meta_ref, _), (r, a, meta, _) = _run_both(sc, dev, sh_degree, bg, mode)
+    dr = (r.cpu().double() - r_ref).abs()
+    da = (a.cpu().double() - a_ref).abs()
+    # f32 vs f64: a handful of pixels may flip a 1/255 skip or a radius ceil; bound both the
+    # bulk (tight) and the worst case (one splat's worth)
+    assert dr.mean() < 2e-5 and da.mean() < 2e-5, (dr.mean(), da.mean())
+    assert torch.quantile(dr.flatten(), 0.999) < 5e-4
+    assert dr.max() < 2e-2 and da.max() < 2e-2
+    assert a_ref.max() > 0.5      # the scene is not trivially empty
+
+
+@pytest.mark.parametrize("mode,bg,sh_degree", [("classic", True, 3), ("antialiased", False, 3), ("classic", True, 0)])
+def test_rasterization_backward_matches_autograd_oracle(dev, mode, bg, sh_degree):
+    sc = small_scene(n=350, seed=8, big=True, width=64, height=48)
+    (r_ref, a_ref, _, leaves), (r, a, _, gl) = _run_both(sc, dev, sh_degree, bg, mode)
+    gen = torch.Generator().manual_seed(2)
+    wr = torch.randn(r_ref.shape, generator=gen).double()
+    wa = torch.randn(a_ref.shape, generator=gen).double()
+    ((r_ref * wr).sum() + (a_ref * wa).sum()).backward()
+    ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        e = rel_err(gl[k].grad.cpu(), leaves[k].grad)
+        assert e < 2e-3, (k, e)
+
+
+def test_absgrad_record(dev):
+    sc = small_scene(n=200, seed=9, big=True)
+    (_, _, _, _), (r, a, meta, gl) = _run_both(sc, dev, 3, True, "classic", absgrad=True)
+    r.sum().backward()
+    v = meta["v_splats"]
+    assert (v[..., 9] + 1e-12 >= v[..., 0].abs()).all() and (v[..., 10] + 1e-12 >= v[..., 1].abs()).all()
+    assert float(v[..., 9].sum()) > 0
+
+
+# -------------------------------------------------------------------------------- loss
+def test_loss_fwd_bwd_matches_oracle(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    C, H, W = 2, 45, 70          # not multiples of the tile: exercises the zero padding
+    a = torch.rand(C, H, W, 3, generator=g)
+    b = (a + 0.2 * torch.randn(C, H, W, 3, generator=g)).clamp(0, 1)
+    ad = a.double().requires_grad_(True)
+    L = O.photometric_loss(ad, b.double(), 0.2)
+    L.backward()
+    sums, scratch = ops.loss_fwd(a.to(dev), b.to(dev))
+    Lg = float(ops.loss_value(sums, C * H * W * 3, 0.2))
+    v = ops.loss_bwd(a.to(dev), b.to(dev), scratch, 0.2, 1.0)
+    assert abs(Lg - float(L)) < 1e-5 * max(1.0, abs(float(L)))
+    assert rel_err(v.cpu(), ad.grad) < 1e-4
+
+
+# -------------------------------------------------------------------------------- Adam
+def test_adam_matches_oracle_and_torch(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(1000, 3), (1000, 4), (1000, 3), (1000, 1), (1000, 3), (1000, 45)]
+    lrs = [1.6e-4, 1e-3, 5e-3, 5e-2, 2.5e-3, 1.25e-4]
+    P = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.double().clone() for p in P]
+    M = [torch.zeros_like(p) for p in ref]
+    V = [torch.zeros_like(p) for p in ref]
+    gp = [p.to(dev) for p in P]
+    gm = [torch.zeros_like(p) for p in gp]
+    gv = [torch.zeros_like(p) for p in gp]
+    tp = [torch.nn.Parameter(p.clone()) for p in P]
+    opt = torch.optim.Adam([{"params": [t], "lr": lr} for t, lr in zip(tp, lrs)], eps=1e-15)
+    for step in range(1, 6):
+        G = [torch.randn(s, generator=g) * (10.0 ** float(torch.randint(-6, 0, (1,), generator=g))) for s in shapes]
+        for i in range(6):
+            ref[i], M[i], V[i] = O.adam_step(ref[i], G[i].double(), M[i], V[i], step, lrs[i])
+            tp[i].grad = G[i].clone()
+        opt.step()
+        # only the first 900 rows are live: the tail must stay untouched
+        ops.adam_step(gp, [x.to(dev) for x in G], gm, gv, lrs, step, numel=[900 * s[1] for s in shapes])
+    for i in range(6):
+        assert rel_err(gp[i][:900].cpu(), ref[i][:900]) < 1e-6
+        assert rel_err(gp[i][:900].cpu(), tp[i].detach()[:900]) < 1e-6
+        assert torch.equal(gp[i][900:].cpu(), P[i][900:])
+
+
+# ----------------------------------------------------------------------------- densify
+def test_densify_decisions_and_surgery(dev):
+    from mi3dgs import trainer
+    sc = small_scene(n=1000, seed=10)
+    sc.params["scales"][:300] = math.log(0.005)      # below grow_scale3d: duplicate candidates
+    sc.params["opacities"][::17] = -6.0              # below prune_opa
+    g = sc.to(dev)
+    img = torch.rand(2, sc.height, sc.width, 3, device=dev)
+    cfg = trainer.TrainConfig(capacity=3000, reset_every=3000)
+    tr = trainer.Trainer(g.params, g.viewmats, g.Ks, img, sc.width, sc.height, cfg)
+    gen = torch.Generator().manual_seed(5)
+    tr.stats["grad2d"][:1000] = (torch.rand(1000, generator=gen) * 6e-4).to(dev)
+    tr.stats["count"][:1000] = torch.randint(0, 3, (1000,), generator=gen).float().to(dev)
+    # give every group a recognisable Adam state
+    for gname in trainer.GROUPS:
+        tr.model.state(gname, "m").fill_(1.0)
+        tr.model.state(gname, "v").fill_(2.0)
+    P = {k: v.clone() for k, v in sc.params.items()}
+    state = dict(grad2d=tr.stats["grad2d"][:1000].cpu().double(), count=tr.stats["count"][:1000].cpu().double())
+    tr.step_count = 3100            # > reset_every: the too-big rule is active
+    dup, split, prune0 = O.strategy_masks(state, P["scales"].double().exp(), torch.sigmoid(P["opacities"].double()),
+                                          3100)
+    # prune is evaluated on the grown set: split children have scale / 1.6
+    s_eff = P["scales"].double().exp().amax(-1) / torch.where(split, 1.6, 1.0)
+    prune = (torch.sigmoid(P["opacities"].double()) < 0.005) | (s_eff > 0.1)
+    info = tr.refine(do_grow=True)
+    exp_n = int(((~prune) * (1 + (dup | split).long())).sum())
+    assert info["n_after"] == exp_n == tr.model.n
+    assert info["n_dup"] == int((dup & ~prune).sum()) and info["n_split"] == int((split & ~prune).sum())
+    assert info["n_dup"] > 0 and info["n_split"] > 0 and info["n_prune"] == int(prune.sum())
+    # survivors keep order; untouched ones keep params and Adam state bit for bit
+    keep_plain = (~prune) & ~dup & ~split
+    offs = torch.cumsum((~prune).long() * (1 + (dup | split).long()), 0) - (~prune).long() * (1 + (dup | split).long())
+    idx = offs[keep_plain]
+    for gname, w in zip(trainer.GROUPS, trainer.WIDTHS):
+        got = tr.model.banks[tr.model.cur][gname]["p"][: tr.model.n].cpu()
+        assert torch.equal(got[idx], P[gname].reshape(1000, w)[keep_plain])
+        assert torch.equal(tr.model.state(gname, "m").cpu()[idx], torch.ones(len(idx), w))
+    # duplicates: original keeps state, copy has zero state and identical params
+    d_idx = offs[dup & ~prune]
+    means = tr.model.p("means").cpu()
+    assert torch.equal(means[d_idx], means[d_idx + 1])
+    assert float(tr.model.state("means", "m").cpu()[d_idx].min()) == 1.0
+    assert float(tr.model.state("means", "m").cpu()[d_idx + 1].abs().max()) == 0.0
+    # splits: two children, scale - log 1.6, zero state, displaced means
+    s_idx = offs[split & ~prune]
+    sc_new = tr.model.p("scales").cpu()
+    assert torch.allclose(sc_new[s_idx], P["scales"][split & ~prune] - math.log(1.6), atol=1e-6)
+    assert torch.allclose(sc_new[s_idx + 1], sc_new[s_idx])
+    assert float(tr.model.state("scales", "v").cpu()[s_idx].abs().max()) == 0.0
+    disp = (means[s_idx] - P["means"][split & ~prune]).norm(dim=-1)
+    assert float(disp.min()) > 0 and float((means[s_idx] - means[s_idx + 1]).norm(dim=-1).min()) > 0
+    # displacement is a sample of N(0, R S^2 R^T): |disp| / max_scale should be O(1)
+    ratio = disp / P["scales"][split & ~prune].exp().amax(-1)
+    assert 0.3 < float(ratio.median()) < 3.0
+    # statistics are reset
+    assert float(tr.stats["grad2d"].abs().max()) == 0.0
+    # opacity reset
+    tr.reset_opacity()
+    thr = math.log(0.01 / 0.99)
+    assert float(tr.model.p("opacities").max()) <= thr + 1e-6
+    assert float(tr.model.state("opacities", "m").abs().max()) == 0.0
+
+
+def test_scale_reg_matches_oracle(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    s = (torch.randn(500, 3, generator=g) * 1.5).double().requires_grad_(True)
+    L = O.scale_regularisation(s.exp())
+    L.backward()
+    v = torch.zeros(500, 3, device=dev)
+    ls = torch.zeros(1, device=dev)
+    ops.scale_reg(s.detach().float().to(dev), 0.1, 10.0, v, ls)
+    assert abs(float(ls) - float(L)) < 1e-4 * float(L)
+    assert rel_err(v.cpu(), s.grad) < 1e-4
+
+
+# ---------------------------------------------------------------- end to end: training
+def test_training_recovers_target(dev):
+    """Render targets from one Gaussian set, perturb it, train: the loss must fall steadily
+    (end-to-end check in lieu of a reference golden image)."""
+    from mi3dgs import trainer
+    sc = small_scene(n=1500, seed=11, big=True, width=96, height=64, n_views=4, fx=90.0)
+    g = sc.to(dev)
+    tr0 = trainer.Trainer(g.params, g.viewmats, g.Ks, torch.zeros(4, 64, 96, 3, device=dev), 96, 64,
+                          trainer.TrainConfig(densify=False))
+    imgs = torch.cat([tr0.render(g.viewmats[i], g.Ks[i])[0].clone() for i in range(4)])
+    gen = torch.Generator().manual_seed(7)
+    P = {k: v.clone() for k, v in g.params.items()}
+    P["means"] = P["means"] + 0.02 * torch.randn(1500, 3, generator=gen).to(dev)
+    P["sh0"] = P["sh0"] + 0.3 * torch.randn(1500, 1, 3, generator=gen).to(dev)
+    cfg = trainer.TrainConfig(max_steps=300, densify=False, sh_degree_interval=1)
+    tr = trainer.Trainer(P, g.viewmats, g.Ks, imgs, 96, 64, cfg)
+    first = sum(tr.step(i % 4, want_loss=True) for i in range(4)) / 4
+    for i in range(4, 296):
+        tr.step(i % 4)
+    last = sum(tr.step(i % 4, want_loss=True) for i in range(4)) / 4
+    assert last < 0.5 * first, (first, last)
