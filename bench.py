@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3DGS training iterations/s (+ render FPS) at 1080p on MI355X.
+
+Contract (one JSON line on stdout from rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank
+  trains its own independent scene (BASELINE.json configs[3]: "8 independent scenes, one per
+  GPU") -> weak scaling, no data-path collective, RCCL barrier + max-over-ranks timing.
+
+A "step" is one full training iteration on one 1920x1080 view of the S2 "garden-like"
+synthetic scene (2 M Gaussians, SH degree 3): project+SH -> tile binning ->
+rasterise -> L1+SSIM loss -> rasterise backward -> project backward (+ densify statistics)
+-> Adam.  Inputs (Gaussians, cameras, target images) are resident in HBM before timing.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pipeline-pointcloud_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+F32_PEAK_TFLOPS = 157.3      # f32 MFMA == f32 vector peak
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="garden", choices=["cube", "lego", "garden", "6m"])
+    ap.add_argument("--n", type=int, default=None, help="override the Gaussian count")
+    ap.add_argument("--views", type=int, default=8, help="target views kept resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-profile", action="store_true")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
+    return ap.parse_args()
+
+
+def setup_dist(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif n_gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    return rank, world, local
+
+
+def build_workload(args, rank, dev):
+    from mi3dgs import scenes, trainer
+    kw = {}
+    if args.n:
+        kw["n"] = args.n
+    seed = {"cube": 0, "lego": 1, "garden": 2, "6m": 3}[args.scene] + rank
+    log(f"generating scene {args.scene} seed {seed}")
+    sc = scenes.make_scene(args.scene, seed=seed, **kw)
+    # targets come from a perturbed copy of the SAME Gaussians: the loss is non-trivial but the
+    # optimum is nearby, so Adam does not drive the scene (and the intersection count) away
+    # from the named workload while it is being timed
+    gp = torch.Generator().manual_seed(seed + 100)
+    tgt = scenes.Scene(sc.name, {k: v.clone() for k, v in sc.params.items()}, sc.viewmats, sc.Ks, sc.width, sc.height)
+    for k, sd in (("means", 0.01), ("scales", 0.1), ("opacities", 0.3), ("sh0", 0.1), ("shN", 0.02)):
+        tgt.params[k] += sd * torch.randn(tgt.params[k].shape, generator=gp)
+    V = min(args.views, sc.viewmats.shape[0])
+    step = max(1, sc.viewmats.shape[0] // V)
+    vidx = list(range(0, sc.viewmats.shape[0], step))[:V]
+    g = sc.to(dev)
+    vm, ks = g.viewmats[vidx].contiguous(), g.Ks[vidx].contiguous()
+    # target images: rendered once by this engine from the *other* Gaussian set
+    cfg0 = trainer.TrainConfig(densify=False)
+    tr0 = trainer.Trainer(tgt.to(dev).params, vm, ks, torch.zeros(1, 1, 1, 3, device=dev), sc.width, sc.height, cfg0)
+    imgs = []
+    for i in range(V):
+        imgs.append(tr0.render(vm[i], ks[i])[0].clamp(0, 1).clone())
+        torch.cuda.synchronize()
+        log(f"target view {i}: {int(tr0.last_binning['n_isect'].item())} intersections")
+    imgs = torch.cat(imgs)
+    del tr0
+    torch.cuda.empty_cache()
+    n = g.params["means"].shape[0]
+    cfg = trainer.TrainConfig(
+        max_steps=30_000, capacity=n,
+        # fixed-N workload: statistics are accumulated every step (their cost is in the step),
+        # the every-100-steps refine pass is timed separately below
+        refine_start_iter=10 ** 9,
+        max_isect=None if args.sync_isect else 0)
+    tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
+    tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
+    if not args.sync_isect:
+        # size the intersection buffers once (one sync here, none in the loop): 1.5x the worst view
+        worst = 0
+        tr.cfg.max_isect = None
+        for i in range(V):
+            tr.render(vm[i], ks[i])
+            worst = max(worst, int(tr.last_binning["n_isect"].item()) if hasattr(tr, "last_binning") else 0)
+        tr.cfg.max_isect = int(worst * 1.5) + 1024
+        log(f"intersection capacity {tr.cfg.max_isect} (worst view {worst})")
+    return sc, tr, V
+
+
+class StageTimer:
+    def __init__(self):
+        self.events = {}
+
+    def __call__(self, name, thunk):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        thunk()
+        e.record()
+        self.events.setdefault(name, []).append((s, e))
+
+    def summary(self, iters):
+        out = {}
+        for name, evs in self.events.items():
+            tot = sum(s.elapsed_time(e) for s, e in evs)
+            out[name] = dict(ms_per_step=tot / iters, calls_per_step=len(evs) / iters)
+        return out
+
+
+def cpu_baseline_cpu_tensors(P, vm, K, gt, W, H, crop_div=6):
+    """One training step of the CPU oracle (a port: the reference has no CPU rasteriser) on a
+    bounded sample, timed in three legs so that the extrapolation is explicit:
+      A  project + SH forward over ALL Gaussians             (scales with N, not with the frame)
+      B  binning + rasterise fwd + L1/SSIM + rasterise bwd on a centred (W/d x H/d) crop
+      C  project + SH backward over ALL Gaussians
+    full-frame step time = A + C + d*d * B.  Adam is not included (the oracle's is a 1-liner)."""
+    from oracle import gs_oracle as O
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    cw, ch = W // crop_div, H // crop_div
+    x0, y0 = (W - cw) // 2, (H - ch) // 2
+    Kc = K.clone()
+    Kc[0, 2] -= x0
+    Kc[1, 2] -= y0
+    gtc = gt[y0:y0 + ch, x0:x0 + cw][None]
+    N = P["means"].shape[0]
+    t0 = time.perf_counter()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    op = torch.sigmoid(leaves["opacities"])
+    radii, m2d, dep, con, _ = O.projection(leaves["means"], leaves["quats"], leaves["scales"].exp(), vm[None], Kc[None],
+                                           cw, ch, opacities=op)
+    campos = torch.linalg.inv(vm)[:3, 3]
+    sh = torch.cat([leaves["sh0"], leaves["shN"]], dim=1)
+    cols = torch.clamp(O.spherical_harmonics(3, leaves["means"] - campos, sh) + 0.5, min=0.0)[None]
+    tA = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rin = [t.detach().requires_grad_(True) for t in (m2d, con, cols, op[None])]
+    tw, th = math.ceil(cw / 16), math.ceil(ch / 16)
+    _, ids, flat = O.isect_tiles(rin[0], radii, dep, 16, tw, th)
+    offs = O.isect_offset_encode(ids, 1, tw, th)
+    r, a, _ = O.rasterize_to_pixels(rin[0], rin[1], rin[2], rin[3], cw, ch, 16, offs, flat)
+    loss = O.photometric_loss(r, gtc, 0.2)
+    loss.backward()
+    tB = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    torch.autograd.backward([m2d, con, cols, op], [rin[0].grad, rin[1].grad, rin[2].grad, rin[3].grad[0]])
+    tC = time.perf_counter() - t0
+    full = tA + tC + crop_div * crop_div * tB
+    return dict(value=1.0 / full, unit="it/s", cores=threads, kind="port",
+                sample=f"oracle/gs_oracle.py float32, one train step: project+SH over all {N} Gaussians fwd {tA:.2f} s "
+                       f"+ bwd {tC:.2f} s, and binning+rasterise+loss fwd/bwd on a {cw}x{ch} centre crop "
+                       f"({ids.numel()} intersections) {tB:.2f} s; extrapolated full frame = A + C + {crop_div**2} x B "
+                       f"= {full:.1f} s; Adam not included")
+
+
+def host_threads() -> int:
+    """Threads the CPU leg may use: the process's CPU affinity, capped at the 16-core share a
+    one-GPU box gets (os.cpu_count() reports the whole host and oversubscribes it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(sc, tr, view, timeout_s=300):
+    """Runs the CPU leg in a child process that never touches the GPU, under a wall-clock
+    limit, so a slow host can not cost the GPU measurement."""
+    import subprocess
+    import tempfile
+    m = tr.model
+    blob = dict(P={g: m.p(g).detach().cpu() for g in ("means", "quats", "scales", "opacities", "sh0", "shN")},
+                vm=tr.viewmats[view].detach().cpu(), K=tr.Ks[view].detach().cpu(),
+                gt=tr.images[view].detach().cpu(), W=sc.width, H=sc.height)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cpu_leg.pt")
+        torch.save(blob, path)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(host_threads()))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", path], env=env,
+                                 capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return dict(value=None, unit="it/s", cores=host_threads(), kind="port",
+                        sample=f"CPU leg exceeded its {timeout_s} s limit on this host and was stopped")
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return dict(value=None, unit="it/s", cores=host_threads(), kind="port",
+                sample="CPU leg failed: " + out.stderr.strip()[-300:])
+
+
+def cpu_leg_main(path):
+    b = torch.load(path, weights_only=False)
+    print(json.dumps(cpu_baseline_cpu_tensors(b["P"], b["vm"], b["K"], b["gt"], b["W"], b["H"])), flush=True)
+
+
+def main():
+    args = parse()
+    if args.cpu_leg:
+        return cpu_leg_main(args.cpu_leg)
+    rank, world, local = setup_dist(args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from mi3dgs import _lib, ops, trainer  # noqa: F401
+
+    sc, tr, V = build_workload(args, rank, dev)
+
+    def sync_all():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    log("warmup")
+    for i in range(args.warmup):
+        tr.step(i % V)
+    sync_all()
+    log("timed region")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step(i % V)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    its = world * args.steps / dt
+    log(f"{its:.2f} it/s")
+
+    # ---- render-only FPS (same scene, SH degree 3), untimed-region extra
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    nr = max(10, args.steps)
+    for i in range(nr):
+        tr.render(tr.viewmats[i % V], tr.Ks[i % V])
+    torch.cuda.synchronize()
+    fps = nr / (time.perf_counter() - t1)
+
+    result = None
+    if rank == 0:
+        n = tr.model.n
+        Px = sc.width * sc.height
+        n_isect = int(tr.last["binning"]["n_isect"].item())
+        n_vis = int((tr.radii[:, :n] > 0).all(-1).sum().item())
+        stages, roof = {}, None
+        if not args.no_stage_profile:
+            # per-kernel launch times: HIP events recorded by the library itself on the launch
+            # stream around every kernel (include/mi3dgs.h: mi3dgs_profile_enable)
+            iters = min(10, max(3, args.steps // 4))
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            for i in range(iters):
+                tr.step(i % V)
+            prof = _lib.profile_read()
+            _lib.profile_enable(False)
+            # ALGORITHMIC bytes per launch (BASELINE.md section 3 / DESIGN.md "Kernels"):
+            # I intersections, n Gaussians, n_vis visible, Px pixels
+            I = n_isect
+            alg = {
+                "project_fwd": n * 44 + n_vis * (192 + 72),
+                "tile_count": n * 8 + n_vis * 16 + n * 12,
+                "rs_hist/depth": n * 4, "rs_scatter/depth": n * 16,
+                "gather_tiles": n * 12,
+                "tile_emit": n * 8 + n_vis * 24 + I * 8,
+                "rs_hist/isect": I * 4, "rs_scatter/isect": I * 16,
+                "tile_offsets": I * 4,
+                "rasterize_fwd": I * 40 + Px * 20,
+                "loss_fwd": Px * (24 + 36), "loss_bwd": Px * (60 + 12),
+                "rasterize_bwd": I * 80 + Px * 32,
+                "project_bwd": n * 44 + n_vis * (192 + 64 + 64) + n * 236,
+                "adam": n * 1652,
+            }
+            for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                e = dict(ms_per_step=ms / iters, launches_per_step=cnt / iters, us_per_launch=1e3 * ms / cnt)
+                if tag in alg:
+                    e["alg_bytes_per_launch"] = alg[tag]
+                    e["alg_GBps"] = alg[tag] / (ms / cnt * 1e-3) / 1e9
+                stages[tag] = e
+            dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["ms_per_step"])
+            ach = stages[dom]["alg_GBps"]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured offline with rocprofv3 --pmc
+            if os.path.isfile(pmc):
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                        traffic=traffic, us_per_launch=stages[dom]["us_per_launch"],
+                        alg_bytes_per_launch=alg[dom], launches_per_step=stages[dom]["launches_per_step"])
+        cpu = None
+        log("stage profile done; cpu baseline")
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(sc, tr, 0)
+            log(f"cpu baseline: {cpu.get('value')}")
+        result = {
+            "metric": "3DGS training iterations/s @1080p (render FPS reported alongside)",
+            "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, "
+                                   "one independent scene per GPU", "gaussians": n, "visible": n_vis,
+                       "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
+                       "parallelism": f"scene-per-gpu x{world}"},
+            "render_fps": fps, "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

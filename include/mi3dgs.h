@@ -53,6 +53,13 @@ int mi3dgs_abi_version(void);
 int mi3dgs_splat_stride(void);
 int mi3dgs_grad_stride(void);
 
+/* Optional per-kernel profiler: while enabled, every kernel launch made by this library is
+ * bracketed by HIP events recorded on the launch stream.  mi3dgs_profile_read waits for
+ * them, writes one text line per kernel tag ("<tag> <launches> <total_ms>\n") into the HOST
+ * buffer `out`, clears the table and returns the bytes written (0 if `cap` is too small). */
+int mi3dgs_profile_enable(int on);
+size_t mi3dgs_profile_read(char* out, size_t cap);
+
 /* ---- per-Gaussian stage --------------------------------------------------------------
  * Replaces gsplat fully_fused_projection_fwd + quat_scale_to_covar_preci +
  * spherical_harmonics_fwd + the exp/sigmoid/clamp glue of gsplat.rasterization()

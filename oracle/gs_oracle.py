@@ -179,17 +179,21 @@ def isect_tiles(means2d, radii, depths, tile_size: int, tile_width: int, tile_he
     tiles = torch.where(vis, (tmax_x - tmin_x) * (tmax_y - tmin_y), torch.zeros_like(tmin_x))
     n_tiles = tile_width * tile_height
     dbits = depths.detach().to(torch.float32).contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    keys, vals = [], []
-    for c in range(C):
-        for g in torch.nonzero(tiles[c] > 0).flatten().tolist():
-            ys = torch.arange(tmin_y[c, g], tmax_y[c, g])
-            xs = torch.arange(tmin_x[c, g], tmax_x[c, g])
-            tid = (ys[:, None] * tile_width + xs[None, :]).flatten() + c * n_tiles
-            keys.append((tid << 32) | dbits[c, g])
-            vals.append(torch.full_like(tid, c * N + g))
-    if keys:
-        keys = torch.cat(keys)
-        vals = torch.cat(vals)
+    # emission order = gsplat's: (camera, Gaussian) major, then tile rows, then tile columns
+    flat_tiles = tiles.flatten()
+    sel = torch.nonzero(flat_tiles > 0).flatten()
+    if sel.numel() > 0:
+        cnt = flat_tiles[sel]
+        w = (tmax_x - tmin_x).flatten()[sel]
+        rep = torch.repeat_interleave(torch.arange(sel.numel()), cnt)
+        start = torch.cumsum(cnt, 0) - cnt
+        local = torch.arange(int(cnt.sum())) - start[rep]
+        ty = tmin_y.flatten()[sel][rep] + local // w[rep]
+        tx = tmin_x.flatten()[sel][rep] + local % w[rep]
+        cam = (sel // N)[rep]
+        tid = cam * n_tiles + ty * tile_width + tx
+        keys = (tid << 32) | dbits.flatten()[sel][rep]
+        vals = sel[rep]
         order = torch.sort(keys, stable=True).indices
         keys, vals = keys[order], vals[order]
     else:

@@ -19,3 +19,76 @@ extern "C" const char* mi3dgs_last_error(void) { return g_err; }
 extern "C" int mi3dgs_abi_version(void) { return 1; }
 extern "C" int mi3dgs_splat_stride(void) { return SPLAT_STRIDE; }
 extern "C" int mi3dgs_grad_stride(void) { return GRAD_STRIDE; }
+
+// ------------------------------------------------------------------ per-kernel profiler
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct ProfRec { int tag; hipEvent_t a, b; };
+std::mutex g_pm;
+bool g_prof_on = false;
+std::vector<std::string> g_tags;
+std::vector<ProfRec> g_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+hipEvent_t g_cur_b = nullptr;
+
+int tag_id(const char* t) {
+    for (size_t i = 0; i < g_tags.size(); i++) if (g_tags[i] == t) return (int)i;
+    g_tags.emplace_back(t);
+    return (int)g_tags.size() - 1;
+}
+}  // namespace
+
+void mi_prof_begin(const char* tag, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_pm);
+    if (g_recs.size() >= (1u << 18)) { g_cur_b = nullptr; return; }
+    hipEvent_t a, b;
+    if (!g_pool.empty()) { a = g_pool.back().first; b = g_pool.back().second; g_pool.pop_back(); }
+    else { if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_cur_b = nullptr; return; } }
+    (void)hipEventRecord(a, st);
+    g_recs.push_back(ProfRec{tag_id(tag), a, b});
+    g_cur_b = b;
+}
+
+void mi_prof_end(hipStream_t st) {
+    if (!g_prof_on || !g_cur_b) return;
+    (void)hipEventRecord(g_cur_b, st);
+    g_cur_b = nullptr;
+}
+
+extern "C" int mi3dgs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_pm);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// Waits for the recorded kernels, then writes one line per tag: "<tag> <launches> <total_ms>\n".
+// Clears the table.  Returns the number of bytes written (0 if `cap` is too small).
+extern "C" size_t mi3dgs_profile_read(char* out, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_pm);
+    std::vector<double> tot(g_tags.size(), 0.0);
+    std::vector<long long> cnt(g_tags.size(), 0);
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            tot[r.tag] += ms;
+            cnt[r.tag] += 1;
+        }
+        g_pool.emplace_back(r.a, r.b);
+    }
+    g_recs.clear();
+    std::string s;
+    char line[256];
+    for (size_t i = 0; i < g_tags.size(); i++) {
+        if (!cnt[i]) continue;
+        snprintf(line, sizeof(line), "%s %lld %.6f\n", g_tags[i].c_str(), cnt[i], tot[i]);
+        s += line;
+    }
+    if (s.size() + 1 > cap) return 0;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return s.size();
+}

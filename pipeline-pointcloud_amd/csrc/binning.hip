@@ -18,6 +18,7 @@
 // from device memory, so the stage runs without a host sync when the caller sizes the
 // intersection buffers by capacity.
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -106,15 +107,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t
 
 // exclusive scan; tmp needs div_up(n, SCAN_TILE) u32.  in may equal out.
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp, uint32_t* total_out,
-                       hipStream_t st) {
+                       hipStream_t st, const char* const* stag = nullptr) {
+    static const char* const dflt[3] = {"scan_reduce", "scan_sums", "scan_final"};
+    if (!stag) stag = dflt;
     if (n == 0) {
         if (total_out) MI_HIP(hipMemsetAsync(total_out, 0, 4, st));
         return 0;
     }
     uint32_t nb = mi_div_up(n, SCAN_TILE);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb, total_out);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp, out);
+    MI_LAUNCH(stag[0], scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
+    MI_LAUNCH(stag[1], scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb, total_out);
+    MI_LAUNCH(stag[2], scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp, out);
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -220,7 +223,17 @@ size_t rs_tmp_u32(uint32_t cap) {
 // LSD radix sort of (key,val) u32 pairs on bits [0, nbits).  Result ends up in (keys_a, vals_a)
 // if the number of passes is even, else in (keys_b, vals_b); returns via *result_in_b.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr,
-                     uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st) {
+                     uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what = "sort") {
+    // profiler tags carry the caller's name so the 2M-key depth sort and the I-key tile sort stay apart
+    static thread_local char htag_buf[48], ctag_buf[48], s0[48], s1[48], s2[48];
+    snprintf(htag_buf, sizeof(htag_buf), "rs_hist/%s", what);
+    snprintf(ctag_buf, sizeof(ctag_buf), "rs_scatter/%s", what);
+    snprintf(s0, sizeof(s0), "scan_reduce/%s", what);
+    snprintf(s1, sizeof(s1), "scan_sums/%s", what);
+    snprintf(s2, sizeof(s2), "scan_final/%s", what);
+    const char* htag = htag_buf;
+    const char* ctag = ctag_buf;
+    const char* const stag3[3] = {s0, s1, s2};
     *result_in_b = 0;
     if (cap == 0 || nbits <= 0) return 0;
     uint32_t B = mi_div_up(cap, RS_TILE);
@@ -234,10 +247,10 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     for (int p = 0; p < passes; p++) {
         int bits = (shift + per <= nbits) ? per : (nbits - shift);
         uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
-        int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st);
+        MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
+        int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, stag3);
         if (rc) return rc;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n_ptr, cap, shift, mask,
+        MI_LAUNCH(ctag, rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n_ptr, cap, shift, mask,
                            hist, B);
         MI_LAUNCH_CHECK();
         uint32_t* t;
@@ -396,15 +409,15 @@ extern "C" int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float*
     BinWs ws;
     size_t need = bin_ws_layout(CN, (uint32_t)max_isect, (uint32_t*)workspace, &ws);
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_count: workspace too small");
-    hipLaunchKernelGGL(tile_count_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, tile_size,
+    MI_LAUNCH("tile_count", tile_count_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, tile_size,
                        tile_width, tile_height, ws.tiles, ws.dkeys_a, ws.ids_a);
     int in_b = 0;
-    int rc = radix_sort_pairs(ws.dkeys_a, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st);
+    int rc = radix_sort_pairs(ws.dkeys_a, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth");
     if (rc) return rc;
     // 4 passes -> result back in a
     uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
     uint32_t* gathered = in_b ? ws.dkeys_a : ws.dkeys_b;   // free key buffer as scratch
-    hipLaunchKernelGGL(gather_u32_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, ws.tiles, sorted_ids, gathered);
+    MI_LAUNCH("gather_tiles", gather_u32_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, ws.tiles, sorted_ids, gathered);
     rc = scan_exclusive_u32(gathered, ws.cum, CN, ws.tmp, (uint32_t*)n_isect_dev, st);
     if (rc) return rc;
     if (tiles_per_gauss)
@@ -433,22 +446,22 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_emit: workspace too small");
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
-    hipLaunchKernelGGL(tile_emit_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a, ws.cum,
+    MI_LAUNCH("tile_emit", tile_emit_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a, ws.cum,
                        radii, splats, tile_size, tile_width, tile_height, cap, tk, fi);
     int nbits = 1;
     while ((1u << nbits) < n_tiles_total) nbits++;
     int in_b = 0;
-    int rc = radix_sort_pairs(tk, fi, ws.tk_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st);
+    int rc = radix_sort_pairs(tk, fi, ws.tk_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st, "isect");
     if (rc) return rc;
     if (in_b) {
         MI_HIP(hipMemcpyAsync(tk, ws.tk_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
         MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
     }
     uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(mi_div_up(g, 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
+    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(g, 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
                        cap, n_tiles_total, isect_offsets);
     if (isect_ids_opt)
-        hipLaunchKernelGGL(isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
+        MI_LAUNCH("isect_ids", isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
                            (const uint32_t*)n_isect_dev, cap, splats, isect_ids_opt);
     MI_LAUNCH_CHECK();
     return 0;

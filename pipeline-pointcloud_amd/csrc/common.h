@@ -64,6 +64,18 @@ int mi_set_error_msg(const char* msg);
         if (!(cond)) return mi_set_error_msg(msg);   \
     } while (0)
 
+// Optional per-kernel profiler (api.cpp): when enabled every MI_LAUNCH is bracketed by HIP
+// events recorded on the launch stream; bench.py reads the table back.
+void mi_prof_begin(const char* tag, hipStream_t st);
+void mi_prof_end(hipStream_t st);
+
+#define MI_LAUNCH(tag, kernel, grid, block, shmem, st, ...)               \
+    do {                                                                  \
+        mi_prof_begin(tag, st);                                           \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);  \
+        mi_prof_end(st);                                                  \
+    } while (0)
+
 static inline int mi_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- wave64 reductions via DPP (no LDS traffic).  Result valid in lane 63.

@@ -152,7 +152,7 @@ extern "C" int mi3dgs_densify_decide(int N, const float* scales_log, const float
                                      int check_too_big, uint8_t* flags, uint32_t* out_count, void* stream) {
     if (N <= 0) return 0;
     MI_REQUIRE(!do_grow || (stat_grad2d && stat_count), "densify_decide: growing needs the running statistics");
-    hipLaunchKernelGGL(densify_decide_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
+    MI_LAUNCH("densify_decide", densify_decide_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
                        opacities_logit, stat_grad2d, stat_count, grow_grad2d, grow_scale3d_abs, prune_opa,
                        prune_scale3d_abs, do_grow, check_too_big, flags, out_count);
     MI_LAUNCH_CHECK();
@@ -174,7 +174,7 @@ extern "C" int mi3dgs_densify_scatter(int N, const float* const* params_in, cons
         MI_REQUIRE(b.in[g] && b.in_m[g] && b.in_v[g] && b.out[g] && b.out_m[g] && b.out_v[g],
                    "densify_scatter: null buffer");
     }
-    hipLaunchKernelGGL(densify_scatter_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, b, flags,
+    MI_LAUNCH("densify_scatter", densify_scatter_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, b, flags,
                        offsets, (uint32_t)capacity, seed);
     MI_LAUNCH_CHECK();
     return 0;
@@ -184,7 +184,7 @@ extern "C" int mi3dgs_densify_scatter(int N, const float* const* params_in, cons
 extern "C" int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_logit, float* exp_avg, float* exp_avg_sq,
                                     void* stream) {
     if (N <= 0) return 0;
-    hipLaunchKernelGGL(reset_opacity_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+    MI_LAUNCH("reset_opacity", reset_opacity_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
                        opacities_logit, max_logit, exp_avg, exp_avg_sq);
     MI_LAUNCH_CHECK();
     return 0;

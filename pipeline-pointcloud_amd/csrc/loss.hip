@@ -166,7 +166,7 @@ extern "C" int mi3dgs_loss_fwd(int C, int height, int width, const float* render
                                float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream) {
     MI_REQUIRE(C > 0 && height > 0 && width > 0, "loss_fwd: bad sizes");
     dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
-    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
+    MI_LAUNCH("loss_fwd", loss_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
                        dm_dsigma1, dm_dsigma12, sums);
     MI_LAUNCH_CHECK();
     return 0;
@@ -181,7 +181,7 @@ extern "C" int mi3dgs_loss_bwd(int C, int height, int width, const float* render
     float w_l1 = loss_scale * (1.f - ssim_lambda) / M;
     float w_ssim = -loss_scale * ssim_lambda / M;
     dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
+    MI_LAUNCH("loss_bwd", loss_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
                        dm_dsigma1, dm_dsigma12, w_l1, w_ssim, v_render);
     MI_LAUNCH_CHECK();
     return 0;

@@ -132,7 +132,7 @@ extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* con
     if (blocks == 0) return 0;
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(AD_THREADS), 0, (hipStream_t)stream, a, beta1, beta2, eps,
+    MI_LAUNCH("adam", adam_kernel, dim3(blocks), dim3(AD_THREADS), 0, (hipStream_t)stream, a, beta1, beta2, eps,
                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
     MI_LAUNCH_CHECK();
     return 0;
@@ -141,7 +141,7 @@ extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* con
 extern "C" int mi3dgs_scale_reg(int N, const float* scales_log, float weight, float max_ratio, float* v_scales,
                                 float* loss_sum, void* stream) {
     if (N <= 0) return 0;
-    hipLaunchKernelGGL(scale_reg_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
+    MI_LAUNCH("scale_reg", scale_reg_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
                        weight, max_ratio, v_scales, loss_sum);
     MI_LAUNCH_CHECK();
     return 0;

@@ -523,7 +523,7 @@ extern "C" int mi3dgs_project_fwd(int C, int N, const float* means, const float*
     MI_REQUIRE(color_mode == 0 || colors, "project_fwd: colour mode needs colors");
     if (N == 0) return 0;
     long long total = (long long)C * N;
-    hipLaunchKernelGGL(project_fwd_kernel, dim3(mi_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
+    MI_LAUNCH("project_fwd", project_fwd_kernel, dim3(mi_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
                        quats, scales, opacities, sh0, shN, colors, color_mode, sh_degree, viewmats, Ks, width, height,
                        eps2d, near_plane, far_plane, radius_clip, flags, radii, splats);
     MI_LAUNCH_CHECK();
@@ -542,7 +542,7 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
     MI_REQUIRE(v_means && v_quats && v_scales, "project_bwd: v_means/v_quats/v_scales required");
     MI_REQUIRE(color_mode != 0 || (v_sh0 && v_shN), "project_bwd: SH mode needs v_sh0/v_shN");
     if (N == 0) return 0;
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
+    MI_LAUNCH("project_bwd", project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
                        quats, scales, opacities, sh0, shN, color_mode, sh_degree, viewmats, Ks, width, height, eps2d,
                        flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_colors,
                        stat_grad2d, stat_count, stat_radii, stat_use_abs);

@@ -236,11 +236,11 @@ extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size,
     int n_tiles = C * tile_width * tile_height;
     hipStream_t st = (hipStream_t)stream;
     if (backgrounds)
-        hipLaunchKernelGGL(rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
                            tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
                            alphas, last_ids);
     else
-        hipLaunchKernelGGL(rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
                            tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
                            alphas, last_ids);
     MI_LAUNCH_CHECK();
@@ -258,7 +258,7 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
     int n_tiles = C * tile_width * tile_height;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BWD(BG, AG)                                                                                            \
-    hipLaunchKernelGGL((rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,   \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,   \
                        tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas,     \
                        last_ids, v_render, v_alphas, v_splats)
     if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }

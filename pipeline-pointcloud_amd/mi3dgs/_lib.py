@@ -27,6 +27,8 @@ _SIGNATURES = {
     "mi3dgs_abi_version": (_i, []),
     "mi3dgs_splat_stride": (_i, []),
     "mi3dgs_grad_stride": (_i, []),
+    "mi3dgs_profile_enable": (_i, [_i]),
+    "mi3dgs_profile_read": (_sz, [C.c_char_p, _sz]),
     "mi3dgs_project_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _i,
                                 _f, _f, _f]),
     "mi3dgs_project_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
@@ -83,5 +85,29 @@ def check(rc: int) -> None:
         raise Mi3dgsError(msg.decode() if msg else f"mi3dgs call failed with code {rc}")
 
 
+def profile_enable(on: bool) -> None:
+    lib().mi3dgs_profile_enable(int(bool(on)))
+
+
+def profile_read() -> dict:
+    """{kernel tag: (launches, total_ms)} since the last read; waits for the kernels."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().mi3dgs_profile_read(buf, len(buf))
+    out = {}
+    for line in buf.raw[:n].decode().splitlines():
+        tag, cnt, ms = line.rsplit(" ", 2)
+        out[tag] = (int(cnt), float(ms))
+    return out
+
+
+# Optional stage hook (used by bench.py to bracket each C-ABI call with HIP events on the
+# launch stream).  hook(name, thunk) must call thunk() exactly once.
+STAGE_HOOK = None
+
+
 def call(name: str, *args) -> None:
-    check(getattr(lib(), name)(*args))
+    fn = getattr(lib(), name)
+    if STAGE_HOOK is None:
+        check(fn(*args))
+    else:
+        STAGE_HOOK(name, lambda: check(fn(*args)))

@@ -160,6 +160,7 @@ class Trainer:
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
+        self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids
 
     @torch.no_grad()
