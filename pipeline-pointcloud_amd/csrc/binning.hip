@@ -159,6 +159,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ hist_scanned, uint32_t B) {
     __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t delta[256];
+    __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
+    __shared__ uint32_t lds4[4];
     uint32_t n = live_count(n_ptr, cap);
     uint32_t block_base = blockIdx.x * RS_TILE;
     if (block_base >= n) return;
@@ -190,16 +193,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         loc[r] = pre + rank;
     }
     __syncthreads();
+    // Stage the block's pairs in LDS in (digit, input order) order, then stream them out:
+    // consecutive threads then store consecutive addresses inside each digit run, instead of
+    // one scattered 4-byte store per lane (measured 5.3x HBM write amplification before).
+    uint32_t tot;
     {
-        // thread d: turn per-wave totals into global bases
         uint32_t d = threadIdx.x;
-        uint32_t g = hist_scanned[d * B + blockIdx.x];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t c = cnt[i][d];
-            cnt[i][d] = g;
-            g += c;
-        }
+        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        uint32_t lstart = block_excl_scan_u32(c0 + c1 + c2 + c3, &tot, lds4);   // first local slot of digit d
+        cnt[0][d] = lstart; cnt[1][d] = lstart + c0; cnt[2][d] = lstart + c0 + c1; cnt[3][d] = lstart + c0 + c1 + c2;
+        delta[d] = hist_scanned[d * B + blockIdx.x] - lstart;                    // global = local + delta[digit]
     }
     __syncthreads();
 #pragma unroll
@@ -207,10 +210,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t idx = wbase + r * 64 + lane;
         if (idx < n) {
             uint32_t d = (key[r] >> shift) & mask;
-            uint32_t pos = cnt[w][d] + loc[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[idx];
+            uint32_t slot = cnt[w][d] + loc[r];
+            skey[slot] = key[r];
+            sval[slot] = vals_in[idx];
         }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tot; j += RS_THREADS) {
+        uint32_t k = skey[j];
+        uint32_t pos = j + delta[(k >> shift) & mask];
+        keys_out[pos] = k;
+        vals_out[pos] = sval[j];
     }
 }
 
@@ -301,32 +311,64 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(uint32_t n, const uint3
     if (i < n) dst[i] = src[index[i]];
 }
 
-// thread per depth-sorted position: write its tile keys at cum[i]...
+// One block per 256 consecutive depth-sorted Gaussians.  Their output range is contiguous
+// ([cum[first], cum[last] + tiles[last])), so the block walks it with consecutive threads on
+// consecutive slots (coalesced 1-KiB stores) and finds each slot's Gaussian by binary search
+// over the 256 exclusive offsets held in LDS.  (Thread-per-Gaussian emission measured 3.5x
+// HBM write amplification.)
 __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N, const uint32_t* __restrict__ sorted_ids,
                                                         const uint32_t* __restrict__ cum,
                                                         const int32_t* __restrict__ radii,
                                                         const float* __restrict__ splats, int tile_size, int tw, int th,
                                                         uint32_t cap, uint32_t* __restrict__ tile_keys,
                                                         uint32_t* __restrict__ flat_ids) {
+    __shared__ uint32_t s_cum[257];
+    __shared__ uint32_t s_id[256], s_key0[256];
+    __shared__ int s_w[256];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CN) return;
-    uint32_t idx = sorted_ids[i];
-    int2 r = *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
-    if (r.x <= 0 || r.y <= 0) return;
-    const float* s = splats + (size_t)idx * SPLAT_STRIDE;
-    int x0, y0, x1, y1;
-    tile_bbox(s[SP_X], s[SP_Y], r.x, r.y, tile_size, tw, th, x0, y0, x1, y1);
-    uint32_t cam = idx / N;
-    uint32_t base_key = cam * (uint32_t)(tw * th);
-    uint32_t o = cum[i];
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (o < cap) {
-                tile_keys[o] = base_key + (uint32_t)(y * tw + x);
-                flat_ids[o] = idx;
-            }
-            o++;
+    uint32_t my_cum = 0, my_n = 0, idx = 0, key0 = 0;
+    int w = 1;
+    if (i < CN) {
+        idx = sorted_ids[i];
+        my_cum = cum[i];
+        int2 r = *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
+        if (r.x > 0 && r.y > 0) {
+            const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
+            int x0, y0, x1, y1;
+            tile_bbox(sp[SP_X], sp[SP_Y], r.x, r.y, tile_size, tw, th, x0, y0, x1, y1);
+            w = max(x1 - x0, 1);
+            my_n = (uint32_t)((x1 - x0) * (y1 - y0));
+            key0 = (idx / N) * (uint32_t)(tw * th) + (uint32_t)(y0 * tw + x0);
         }
+    }
+    s_cum[threadIdx.x] = my_cum;
+    s_id[threadIdx.x] = idx;
+    s_key0[threadIdx.x] = key0;
+    s_w[threadIdx.x] = w;
+    // the last live thread of the block publishes the end of the block's range
+    uint32_t last = min(CN - blockIdx.x * blockDim.x, blockDim.x) - 1;
+    if (threadIdx.x == last) s_cum[256] = my_cum + my_n;
+    __syncthreads();
+    uint32_t begin = s_cum[0], end = s_cum[256];
+    if (threadIdx.x > last) s_cum[threadIdx.x] = end;     // padding so the search never lands on a dead slot
+    __syncthreads();
+    for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
+        // largest g with s_cum[g] <= p
+        uint32_t lo = 0, hi = 255;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_cum[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        uint32_t local = p - s_cum[lo];
+        int ww = s_w[lo];
+        uint32_t row = local / (uint32_t)ww;
+        uint32_t col = local - row * (uint32_t)ww;
+        if (p < cap) {
+            tile_keys[p] = s_key0[lo] + row * (uint32_t)tw + col;
+            flat_ids[p] = s_id[lo];
+        }
+    }
 }
 
 // offsets[t] = first sorted position whose key >= t   (t in [0, n_tiles_total))

@@ -95,6 +95,29 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// Nine wave64 sums at once, results in lane 63.  One fused v_add_f32_dpp per value and step,
+// the nine independent chains interleaved: a DPP read needs 2 wait states after the VALU write
+// of the same register, which the 8 other adds in between provide (the leading s_nop covers
+// the compiler's last write).  hipcc turns the builtin form into mov_dpp + zero-init + add.
+#define MI_DPP9(ctrl)                                                           \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n"  \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n"  \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl "\n"  \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n"  \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
+__device__ __forceinline__ void wave_sum9_to_lane63(float& a, float& b, float& c, float& d, float& e, float& f,
+                                                    float& g, float& h, float& i) {
+    asm volatile("s_nop 1\n"
+                 MI_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 MI_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 MI_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 MI_DPP9("row_mirror row_mask:0xf bank_mask:0xf")
+                 MI_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 MI_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+}
+
 __device__ __forceinline__ float wave_sum_all(float v) {
     v = wave_sum_to_lane63(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

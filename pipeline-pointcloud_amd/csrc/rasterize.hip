@@ -18,6 +18,17 @@
 // I*64 B gather + Px*20 B fwd, I*64 B gather + I*64 B atomics + Px*36 B bwd.
 #include "common.h"
 
+#ifdef MI_RASTER_STATS
+// debug build only (make STATS=1): [0] (wave,splat) visits, [1] visits with >=1 live lane,
+// [2] live lanes, [3] slots flushed with atomics, [4] slots staged
+__device__ unsigned long long g_raster_stats[8];
+extern "C" int mi3dgs_debug_raster_stats(unsigned long long* host_out, int reset) {
+    if (host_out) (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_raster_stats), sizeof(g_raster_stats));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 namespace {
 
 constexpr int TILE = 16;
@@ -60,22 +71,45 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
             float4 a = rec[0], bb = rec[1];
             float c = reinterpret_cast<const float*>(rec)[SP_B];
             sA[threadIdx.x] = a; sB[threadIdx.x] = bb; sC[threadIdx.x] = c;
+        } else {
+            // pad the tail with zero-opacity records so the unrolled body needs no bounds test
+            sA[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); sB[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sC[threadIdx.x] = 0.f;
         }
         __syncthreads();
         int bsz = min(BLOCK, end - bs);
-        if (!done) {
-            for (int k = 0; k < bsz; k++) {
-                float4 a = sA[k], bb = sB[k];
+        // The per-splat body is branch-free (predicated): divergent `continue`/`break` made this
+        // loop issue more SALU (exec-mask bookkeeping) than VALU instructions.  Only two
+        // wave-uniform branches remain: "whole wave finished" per group of 4 splats and
+        // "no lane of the wave is touched by this splat".
+        for (int k0 = 0; k0 < bsz; k0 += 4) {
+            if (__ballot(!done) == 0ull) break;
+            // independent part first (4 records, 4 exps in flight), dependent T chain after
+            float4 bb[4];
+            float cb[4], alpha[4];
+            bool hit[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float4 a = sA[k0 + u];
+                bb[u] = sB[k0 + u];
+                cb[u] = sC[k0 + u];
                 float dx = a.x - px, dy = a.y - py;
-                float sigma = 0.5f * (a.z * dx * dx + bb.x * dy * dy) + a.w * dx * dy;
-                float alpha = fminf(MAX_ALPHA, bb.y * __expf(-sigma));
-                if (sigma < 0.f || alpha < ALPHA_THRESHOLD) continue;
-                float nT = T * (1.f - alpha);
-                if (nT <= T_STOP) { done = true; break; }
-                float wgt = alpha * T;
-                r += bb.z * wgt; g += bb.w * wgt; b += sC[k] * wgt;
-                cur = bs + k;
-                T = nT;
+                float sigma = 0.5f * (a.z * dx * dx + bb[u].x * dy * dy) + a.w * dx * dy;
+                alpha[u] = fminf(MAX_ALPHA, bb[u].y * __expf(-sigma));
+                hit[u] = sigma >= 0.f && alpha[u] >= ALPHA_THRESHOLD;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                bool ok = !done && hit[u];
+                if (__ballot(ok) == 0ull) continue;
+                float nT = T * (1.f - alpha[u]);
+                bool stop = ok && nT <= T_STOP;
+                done = done || stop;
+                ok = ok && !stop;
+                float wgt = ok ? alpha[u] * T : 0.f;
+                r += bb[u].z * wgt; g += bb[u].w * wgt; b += cb[u] * wgt;
+                cur = ok ? bs + k0 + u : cur;
+                T = ok ? nT : T;
             }
         }
     }
@@ -172,33 +206,39 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
             float vis = __expf(-sigma);
             float alpha = fminf(MAX_ALPHA, bb.y * vis);
             bool valid = (sidx <= bin_final) && !(sigma < 0.f || alpha < ALPHA_THRESHOLD);
-            if (__ballot(valid) == 0ull) continue;
-            float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_o = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-            float g_ax = 0.f, g_ay = 0.f;
-            if (valid) {
-                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T *= ra;
-                float fac = alpha * T;
-                g_r = fac * vr0; g_g = fac * vr1; g_b = fac * vr2;
-                float v_alpha = (bb.z * T - buf0 * ra) * vr0 + (bb.w * T - buf1 * ra) * vr1 + (cb * T - buf2 * ra) * vr2;
-                v_alpha += T_final * ra * va;
-                if (HAS_BG) v_alpha -= T_final * ra * bgdot;
-                buf0 += bb.z * fac; buf1 += bb.w * fac; buf2 += cb * fac;
-                if (bb.y * vis <= MAX_ALPHA) {
-                    float v_sigma = -bb.y * vis * v_alpha;
-                    g_ca = 0.5f * v_sigma * dx * dx;
-                    g_cb = v_sigma * dx * dy;
-                    g_cc = 0.5f * v_sigma * dy * dy;
-                    g_x = v_sigma * (a.z * dx + a.w * dy);
-                    g_y = v_sigma * (a.w * dx + bb.x * dy);
-                    g_o = vis * v_alpha;
-                    if (ABSGRAD) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
+#ifdef MI_RASTER_STATS
+            {
+                unsigned long long bm = __ballot(valid);
+                if (lane == 0) {
+                    atomicAdd(&g_raster_stats[0], 1ull);
+                    if (bm) { atomicAdd(&g_raster_stats[1], 1ull); atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(bm)); }
                 }
             }
-            g_x = wave_sum_to_lane63(g_x); g_y = wave_sum_to_lane63(g_y);
-            g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-            g_o = wave_sum_to_lane63(g_o);
-            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+#endif
+            if (__ballot(valid) == 0ull) continue;
+            // Branch-free live part: a dead lane runs it with alpha = 0 (ra = 1, T and buf
+            // unchanged bit for bit, every partial 0), so no exec-mask region is needed.
+            float a_eff = valid ? alpha : 0.f;
+            float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+            T *= ra;
+            float fac = a_eff * T;
+            float g_r = fac * vr0, g_g = fac * vr1, g_b = fac * vr2;
+            float v_alpha = (bb.z * T - buf0 * ra) * vr0 + (bb.w * T - buf1 * ra) * vr1 + (cb * T - buf2 * ra) * vr2;
+            v_alpha += T_final * ra * va;
+            if (HAS_BG) v_alpha -= T_final * ra * bgdot;
+            buf0 += bb.z * fac; buf1 += bb.w * fac; buf2 += cb * fac;
+            float ov = bb.y * vis;
+            bool grad_on = valid && ov <= MAX_ALPHA;
+            float v_sigma = grad_on ? -ov * v_alpha : 0.f;
+            float g_o = grad_on ? vis * v_alpha : 0.f;
+            float g_ca = 0.5f * v_sigma * dx * dx;
+            float g_cb = v_sigma * dx * dy;
+            float g_cc = 0.5f * v_sigma * dy * dy;
+            float g_x = v_sigma * (a.z * dx + a.w * dy);
+            float g_y = v_sigma * (a.w * dx + bb.x * dy);
+            float g_ax = 0.f, g_ay = 0.f;
+            if (ABSGRAD) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
+            wave_sum9_to_lane63(g_x, g_y, g_ca, g_cb, g_cc, g_o, g_r, g_g, g_b);
             if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
             if (lane == 63) {
                 float* o = acc[k];
@@ -215,6 +255,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         for (int s = wv * 64; s < wv * 64 + 64; s += 4) {
             int slot = s + (lane >> 4);
             int comp = lane & 15;
+#ifdef MI_RASTER_STATS
+            if (comp == 0 && slot < bsz) { atomicAdd(&g_raster_stats[4], 1ull); if (touched[slot]) atomicAdd(&g_raster_stats[3], 1ull); }
+#endif
             if (slot < bsz && touched[slot] && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
                 float v = acc[slot][comp];
                 atomicAdd(&v_splats[(size_t)sId[slot] * GRAD_STRIDE + comp], v);
