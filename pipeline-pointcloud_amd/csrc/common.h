@@ -118,6 +118,48 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float& a, float& b, float& c
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
 
+// Eight wave64 sums as a reduce-SCATTER plus a ninth as a plain reduction.  On return every
+// lane l holds in `a` the total of input value number (l >> 3) (a..h = values 0..7), and lane
+// 63 holds the total of `i`.  24 VALU instead of 54: levels 32 and 16 exchange half of the
+// registers with gfx950's v_permlane32_swap / v_permlane16_swap (2 instructions per pair of
+// values), level 8 is a select + row_ror:8, and only ONE register goes through the last
+// three in-row steps.  Checked on hardware by tools/micro/reduce_scatter_test.hip.
+__device__ __forceinline__ void wave_reduce_scatter8_plus1(float& a, float& b, float& c, float& d, float& e, float& f,
+                                                           float& g, float& h, float& i) {
+    const unsigned long long m8 = 0xFF00FF00FF00FF00ull;   // lanes with bit 3 set
+    float t;
+    asm volatile(
+        "s_nop 1\n"
+        "v_permlane32_swap_b32 %0, %4\n v_permlane32_swap_b32 %1, %5\n"
+        "v_permlane32_swap_b32 %2, %6\n v_permlane32_swap_b32 %3, %7\n"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %6\n v_add_f32 %3, %3, %7\n"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n"
+        "s_nop 1\n"
+        "v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_cndmask_b32 %9, %1, %0, %10\n"
+        "v_cndmask_b32 %0, %0, %1, %10\n"
+        "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %0, %9, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "=&v"(t)
+        : "s"(m8));
+}
+
 __device__ __forceinline__ float wave_sum_all(float v) {
     v = wave_sum_to_lane63(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

@@ -238,16 +238,17 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
             float g_y = v_sigma * (a.w * dx + bb.x * dy);
             float g_ax = 0.f, g_ay = 0.f;
             if (ABSGRAD) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
-            wave_sum9_to_lane63(g_x, g_y, g_ca, g_cb, g_cc, g_o, g_r, g_g, g_b);
+            // reduce-scatter: lane l ends with the total of component (l >> 3) in g_x, lane 63
+            // with the total of g_b  ->  ONE 9-lane LDS atomic per (quadrant, splat)
+            wave_reduce_scatter8_plus1(g_x, g_y, g_ca, g_cb, g_cc, g_o, g_r, g_g, g_b);
             if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
-            if (lane == 63) {
-                float* o = acc[k];
-                atomicAdd(&o[GR_X], g_x); atomicAdd(&o[GR_Y], g_y);
-                atomicAdd(&o[GR_CA], g_ca); atomicAdd(&o[GR_CB], g_cb); atomicAdd(&o[GR_CC], g_cc);
-                atomicAdd(&o[GR_OPA], g_o);
-                atomicAdd(&o[GR_R], g_r); atomicAdd(&o[GR_G], g_g); atomicAdd(&o[GR_B], g_b);
-                if (ABSGRAD) { atomicAdd(&o[GR_ABSX], g_ax); atomicAdd(&o[GR_ABSY], g_ay); }
-                touched[k] = 1;
+            {
+                bool last = lane == 63;
+                if ((lane & 7) == 0 || last) atomicAdd(&acc[k][last ? GR_B : (lane >> 3)], last ? g_b : g_x);
+                if (last) {
+                    if (ABSGRAD) { atomicAdd(&acc[k][GR_ABSX], g_ax); atomicAdd(&acc[k][GR_ABSY], g_ay); }
+                    touched[k] = 1;
+                }
             }
         }
         __syncthreads();
