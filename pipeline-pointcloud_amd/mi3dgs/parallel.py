@@ -1,0 +1,148 @@
+"""Multi-GPU modes of the training path, one process per GPU over RCCL.
+
+The reference's multi-GPU branch (source/container/src/main.py:1318-1347) runs gsplat's
+`simple_trainer.py --steps_scaler 1/G --packed --batch-size 1` with `WORLD_SIZE`, `RANK`,
+`LOCAL_RANK`, `MASTER_ADDR`, `MASTER_PORT` exported at main.py:623-655.  Two modes here:
+
+* scene-per-GPU (BASELINE.json configs[3]): independent replicas, no data-path collective;
+  only a barrier brackets the timed region (bench.py).
+* one big scene (configs[4]): Gaussians REPLICATED on every GPU (6 M x 944 B = 5.7 GB, nothing
+  against 288 GB), each rank renders a different image per step, then
+      gradients      : all-reduce, mean over ranks   (every step)
+      densify stats  : all-reduce sum / sum / max    (only when a refine pass runs)
+  so every replica applies the identical Adam step and takes identical densify decisions
+  (same counter-based RNG seed for split samples).  Upstream instead shards Gaussians and
+  all-to-alls projected splats; replication trades 2 * 7/8 * |grad| of xGMI traffic per
+  step for zero forward/backward exchange.
+
+`backend="nccl"` is RCCL on ROCm; the CPU tests run the same code over `gloo`.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .trainer import GROUPS, TrainConfig, Trainer
+
+
+@dataclasses.dataclass
+class DistContext:
+    rank: int
+    world: int
+    local_rank: int
+    group: Optional[object] = None
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None) -> DistContext:
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (what the reference
+    exports at main.py:623-655).  Single-process runs get an inactive context."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")       # reference default, main.py:640
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return DistContext(rank, world, local)
+
+
+def views_for_step(step: int, n_views: int, ctx: DistContext) -> int:
+    """View this rank trains on at global step `step`: a batch of `world` consecutive views of a
+    fixed round-robin order, one per rank, so a full pass touches every view exactly once."""
+    return (step * ctx.world + ctx.rank) % n_views
+
+
+def allreduce_mean_(tensors: Sequence[torch.Tensor], ctx: DistContext) -> None:
+    """In-place mean over ranks.  One collective per tensor, issued back to back (RCCL fuses
+    them on the stream); tensors must be contiguous."""
+    if not ctx.active:
+        return
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ctx.group)
+    inv = 1.0 / ctx.world
+    for t in tensors:
+        t.mul_(inv)
+
+
+def allreduce_stats_(stats: Dict[str, torch.Tensor], ctx: DistContext) -> None:
+    """Densify statistics: gradient-norm accumulators and visibility counts add up, screen
+    radii take the max (gsplat DefaultStrategy state)."""
+    if not ctx.active:
+        return
+    dist.all_reduce(stats["grad2d"], op=dist.ReduceOp.SUM, group=ctx.group)
+    dist.all_reduce(stats["count"], op=dist.ReduceOp.SUM, group=ctx.group)
+    if "radii" in stats:
+        dist.all_reduce(stats["radii"], op=dist.ReduceOp.MAX, group=ctx.group)
+
+
+def batch_scaled_config(cfg: TrainConfig, batch: int) -> TrainConfig:
+    """gsplat simple_trainer's batch-size scaling rule [UPSTREAM-UNVERIFIED] for BS = batch *
+    world: lr *= sqrt(BS), eps /= sqrt(BS), beta_i -> 1 - BS (1 - beta_i), and every step
+    count is divided by BS (the reference passes --steps_scaler 1/G, main.py:1323)."""
+    if batch <= 1:
+        return cfg
+    s = math.sqrt(batch)
+    steps = lambda x: max(1, int(round(x / batch)))      # noqa: E731
+    return dataclasses.replace(
+        cfg,
+        lr_means=cfg.lr_means * s, lr_scales=cfg.lr_scales * s, lr_quats=cfg.lr_quats * s,
+        lr_opacities=cfg.lr_opacities * s, lr_sh0=cfg.lr_sh0 * s, lr_shN=cfg.lr_shN * s,
+        adam_eps=cfg.adam_eps / s,
+        adam_beta1=max(0.0, 1.0 - batch * (1.0 - cfg.adam_beta1)),
+        adam_beta2=max(0.0, 1.0 - batch * (1.0 - cfg.adam_beta2)),
+        max_steps=steps(cfg.max_steps), sh_degree_interval=steps(cfg.sh_degree_interval),
+        refine_start_iter=steps(cfg.refine_start_iter), refine_stop_iter=steps(cfg.refine_stop_iter),
+        reset_every=steps(cfg.reset_every), refine_every=steps(cfg.refine_every))
+
+
+class DataParallelTrainer(Trainer):
+    """Replicated-Gaussian data parallelism: identical parameters on every rank, one view per
+    rank per step, gradient mean and densify-statistics reductions over RCCL."""
+
+    def __init__(self, *args, ctx: Optional[DistContext] = None, **kw):
+        super().__init__(*args, **kw)
+        self.ctx = ctx or init_from_env()
+
+    def _live_grads(self) -> List[torch.Tensor]:
+        m = self.model
+        return [m.grads[g][: m.n] for g in GROUPS]
+
+    def _all_reduce_grads(self):
+        allreduce_mean_(self._live_grads(), self.ctx)
+
+    def refine(self, do_grow: bool = True):
+        n = self.model.n
+        allreduce_stats_({k: v[:n] for k, v in self.stats.items()}, self.ctx)
+        return super().refine(do_grow)
+
+    def step_global(self, global_step: Optional[int] = None, want_loss: bool = False):
+        s = self.step_count if global_step is None else global_step
+        return self.step(views_for_step(s, self.viewmats.shape[0], self.ctx), want_loss)
+
+    def replicas_in_sync(self) -> bool:
+        """True when every rank holds bit-identical parameters (debug / tests)."""
+        if not self.ctx.active:
+            return True
+        ok = True
+        for g in GROUPS:
+            p = self.model.p(g).detach().reshape(-1)
+            lo, hi = p.clone(), p.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.ctx.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.ctx.group)
+            ok = ok and bool(torch.equal(lo, hi))
+        return ok

@@ -39,6 +39,8 @@ class TrainConfig:
     lr_sh0: float = 2.5e-3
     lr_shN: float = 2.5e-3 / 20
     adam_eps: float = 1e-15
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
     scene_scale: float = 1.0
     # DefaultStrategy
     densify: bool = True
@@ -200,7 +202,8 @@ class Trainer:
         self._all_reduce_grads()
         ops.adam_step([m.banks[m.cur][g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS],
                       [m.banks[m.cur][g]["m"] for g in GROUPS], [m.banks[m.cur][g]["v"] for g in GROUPS],
-                      self.lrs(), self.step_count + 1, eps=c.adam_eps, numel=[n * w for w in WIDTHS])
+                      self.lrs(), self.step_count + 1, beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                      numel=[n * w for w in WIDTHS])
         if c.densify:
             self._strategy_post_step()
         self.last = dict(binning=binning, sums=sums)

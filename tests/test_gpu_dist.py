@@ -1,0 +1,78 @@
+"""Replicated-Gaussian data parallelism on the device: two ranks share the one GPU of the test
+box (gloo carries the collectives; on a node it is RCCL, same code path).  Different views
+per rank, so the replicas stay identical ONLY if the gradient mean and the densify-statistics
+reductions are applied."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "pipeline-pointcloud_amd"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        import torch.distributed as dist
+        from helpers import small_scene
+        from mi3dgs import parallel, trainer
+        ctx = parallel.init_from_env(backend="gloo")
+        dev = torch.device("cuda:0")
+        sc = small_scene(n=1200, seed=21, big=True, width=96, height=64, n_views=4, fx=90.0).to(dev)
+        cfg = trainer.TrainConfig(max_steps=100, capacity=6000, refine_start_iter=2, refine_every=4, reset_every=1000,
+                                  grow_grad2d=1e-5, sh_degree_interval=2, seed=5)
+        g = torch.Generator().manual_seed(3)
+        imgs = torch.rand(4, 64, 96, 3, generator=g).to(dev)
+        tr = parallel.DataParallelTrainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, cfg, ctx=ctx)
+        n0 = tr.model.n
+        sync = []
+        for s in range(10):
+            tr.step_global()
+            sync.append(tr.replicas_in_sync())
+        # control: without the reductions the replicas must drift (the test would be vacuous otherwise)
+        tr2 = trainer.Trainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, trainer.TrainConfig(densify=False))
+        tr2.step(rank)
+        p = tr2.model.p("means").reshape(-1).clone()
+        lo, hi = p.clone(), p.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        q.put((rank, dict(sync=all(sync), n0=n0, n=tr.model.n, drift=not torch.equal(lo, hi))))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc() + repr(e)}))
+
+
+@pytest.mark.timeout(300)
+def test_replicas_stay_identical_through_adam_and_refine(dev):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    for r in range(world):
+        assert "error" not in res[r], res[r].get("error")
+        assert res[r]["sync"], "replicas diverged"
+        assert res[r]["drift"], "control run did not drift: the test is vacuous"
+    assert res[0]["n"] == res[1]["n"] and res[0]["n"] != res[0]["n0"], res   # a refine pass really changed N
