@@ -197,6 +197,8 @@ __device__ __forceinline__ void sh_basis_vjp(int deg, float x, float y, float z,
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+constexpr int SH_WAVE_F4 = 64 * 45 / 4;   // one wave's shN slice in float4 units (11 520 B)
+
 // --------------------------------------------------------------------------- forward
 // color_mode: 0 = SH (sh0[N,3] + shN[N,15,3]), 1 = colors[N,3], 2 = colors[C,N,3]
 __global__ __launch_bounds__(256) void project_fwd_kernel(
@@ -206,22 +208,31 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int color_mode, int sh_degree, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip, int flags,
     int32_t* __restrict__ radii, float* __restrict__ splats) {
+    // Each wave's 64 Gaussians own one contiguous 11 520-byte slice of shN.  Reading it as
+    // 45 dword loads per lane at a 180-byte stride made the first version latency/TA bound
+    // (62 VMEM instructions per wave); instead the wave copies the slice with 16-byte loads
+    // into LDS and every lane reads its 45 coefficients from there (stride 45 dwords: odd,
+    // bank-conflict free).
+    __shared__ float4 sSH4[4][SH_WAVE_F4];
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)C * N) return;
-    int c = (int)(idx / N);
-    int n = (int)(idx - (long long)c * N);
-    float4* rec = reinterpret_cast<float4*>(splats + idx * SPLAT_STRIDE);
-    int2* rad = reinterpret_cast<int2*>(radii + idx * 2);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const bool live = idx < (long long)C * N;
+    long long idx_c = live ? idx : (long long)C * N - 1;
+    int c = (int)(idx_c / N);
+    int n = (int)(idx_c - (long long)c * N);
+    float4* rec = reinterpret_cast<float4*>(splats + idx_c * SPLAT_STRIDE);
+    int2* rad = reinterpret_cast<int2*>(radii + idx_c * 2);
 
     Cam cam = load_cam(viewmats, Ks, c);
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float zc = cam.R[6] * mean[0] + cam.R[7] * mean[1] + cam.R[8] * mean[2] + cam.t[2];
-    bool ok = (zc >= near_plane) && (zc <= far_plane);
+    bool ok = live && (zc >= near_plane) && (zc <= far_plane);
     Proj P;
     float opa = 1.f;
     float rx = 0.f, ry = 0.f;
     if (ok) {
-        float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+        float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (long long)n);
+        float q[4] = {q4.x, q4.y, q4.z, q4.w};
         float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
         if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
         float Rq[9], inv_norm, Sw[9];
@@ -247,6 +258,25 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             if (P.m2x + rx <= 0.f || P.m2x - rx >= (float)W || P.m2y + ry <= 0.f || P.m2y - ry >= (float)H) ok = false;
         }
     }
+    // ---- stage this wave's shN slice (wave-uniform decision)
+    bool staged = false;
+    if (color_mode == 0 && sh_degree >= 2) {
+        long long idx0 = idx - lane;                                  // first record of the wave
+        int n0 = (int)(idx0 - (long long)(idx0 / N) * N);
+        bool whole = idx0 + 63 < (long long)C * N && (idx0 / N) == ((idx0 + 63) / N);   // one camera, 64 live lanes
+        const float* src = shN + 45 * (long long)n0;
+        if (whole && (((uintptr_t)src) & 15) == 0 && __ballot(ok) != 0ull) {
+            staged = true;
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
+                int i4 = lane + 64 * j;
+                if (i4 < SH_WAVE_F4) sSH4[wv][i4] = s4[i4];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");            // same-wave LDS hand-off: order only
+    if (!live) return;
     if (!ok) {
         *rad = make_int2(0, 0);
         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,11 +296,20 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         const float* c0 = sh0 + 3 * (long long)n;
         rgb[0] = b[0] * c0[0]; rgb[1] = b[0] * c0[1]; rgb[2] = b[0] * c0[2];
         int nb = (sh_degree + 1) * (sh_degree + 1);
-        const float* cN = shN + 45 * (long long)n;
-        for (int k = 1; k < nb; k++) {
-            rgb[0] += b[k] * cN[3 * (k - 1)];
-            rgb[1] += b[k] * cN[3 * (k - 1) + 1];
-            rgb[2] += b[k] * cN[3 * (k - 1) + 2];
+        if (staged) {
+            const float* cN = reinterpret_cast<const float*>(sSH4[wv]) + 45 * lane;
+            for (int k = 1; k < nb; k++) {
+                rgb[0] += b[k] * cN[3 * (k - 1)];
+                rgb[1] += b[k] * cN[3 * (k - 1) + 1];
+                rgb[2] += b[k] * cN[3 * (k - 1) + 2];
+            }
+        } else {
+            const float* cN = shN + 45 * (long long)n;
+            for (int k = 1; k < nb; k++) {
+                rgb[0] += b[k] * cN[3 * (k - 1)];
+                rgb[1] += b[k] * cN[3 * (k - 1) + 1];
+                rgb[2] += b[k] * cN[3 * (k - 1) + 2];
+            }
         }
         rgb[0] = fmaxf(rgb[0] + 0.5f, 0.f); rgb[1] = fmaxf(rgb[1] + 0.5f, 0.f); rgb[2] = fmaxf(rgb[2] + 0.5f, 0.f);
     } else {
@@ -285,9 +324,262 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 }
 
 // -------------------------------------------------------------------------- backward
-// One thread per Gaussian, loops over cameras; every output is written exactly once.
-// Also accumulates the densify statistics (screen-space gradient norm, visibility count,
-// max screen radius) that gsplat's DefaultStrategy._update_state computes in torch.
+// Shared per-(camera, Gaussian) backward of the geometry: everything except the colour path.
+struct GeoGrad {
+    float vmean[3];
+    float vSw[9];
+    float vopa;
+};
+
+__device__ __forceinline__ void geo_bwd_one_camera(const Cam& cam, const float mean[3], const float Sw[9], int W, int H,
+                                                   float eps2d, int flags, float opa_act, float v_m2x, float v_m2y,
+                                                   float v_cA, float v_cB, float v_cC, float v_op, float v_depth,
+                                                   GeoGrad& G) {
+    Proj P;
+    project_core(cam, mean, Sw, W, H, eps2d, P);
+    float vcov_a = 0.f, vcov_b = 0.f, vcov_c = 0.f;   // symmetric 2x2 grad: [[a, b],[b, c]]
+    if (flags & MI_FLAG_ANTIALIASED) {
+        G.vopa += v_op * P.comp;
+        float v_comp = v_op * opa_act;
+        float det_conic = P.conA * P.conC - P.conB * P.conB;
+        float v_sqr = v_comp * 0.5f / (P.comp + 1e-6f);
+        float om = 1.f - P.comp * P.comp;
+        vcov_a += v_sqr * (om * P.conA - eps2d * det_conic);
+        vcov_b += v_sqr * (om * P.conB);
+        vcov_c += v_sqr * (om * P.conC - eps2d * det_conic);
+    } else {
+        G.vopa += v_op;
+    }
+    // conic = inverse(cov2d): G_cov = -X G_X X, G_X = [[vA, vB/2],[vB/2, vC]]
+    {
+        float xa = P.conA, xb = P.conB, xc = P.conC;
+        float ga = v_cA, gb = 0.5f * v_cB, gc = v_cC;
+        float t00 = xa * ga + xb * gb, t01 = xa * gb + xb * gc;
+        float t10 = xb * ga + xc * gb, t11 = xb * gb + xc * gc;
+        vcov_a -= t00 * xa + t01 * xb;
+        vcov_b -= t00 * xb + t01 * xc;
+        vcov_c -= t10 * xb + t11 * xc;
+    }
+    // cov2d = J Sc J^T ; mean2d
+    float Gm[4] = {vcov_a, vcov_b, vcov_b, vcov_c};
+    float GJ[6], vSc[9], vJ[6];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) GJ[3 * i + j] = Gm[2 * i] * P.J[j] + Gm[2 * i + 1] * P.J[3 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) vSc[3 * i + j] = P.J[i] * GJ[j] + P.J[3 + i] * GJ[3 + j];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            vJ[3 * i + j] = 2.f * (GJ[3 * i] * P.Sc[j] + GJ[3 * i + 1] * P.Sc[3 + j] + GJ[3 * i + 2] * P.Sc[6 + j]);
+    float x = P.mc[0], y = P.mc[1], z = P.mc[2];
+    float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+    float vmc[3];
+    vmc[0] = cam.fx * rz * v_m2x;
+    vmc[1] = cam.fy * rz * v_m2y;
+    vmc[2] = -(cam.fx * x * v_m2x + cam.fy * y * v_m2y) * rz2 + v_depth;
+    if (P.x_in) vmc[0] += -cam.fx * rz2 * vJ[2];
+    else vmc[2] += -cam.fx * rz3 * vJ[2] * P.tx;
+    if (P.y_in) vmc[1] += -cam.fy * rz2 * vJ[5];
+    else vmc[2] += -cam.fy * rz3 * vJ[5] * P.ty;
+    vmc[2] += -cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4] + 2.f * cam.fx * P.tx * rz3 * vJ[2] +
+              2.f * cam.fy * P.ty * rz3 * vJ[5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) G.vmean[i] += cam.R[i] * vmc[0] + cam.R[3 + i] * vmc[1] + cam.R[6 + i] * vmc[2];
+    float tmp[9], acc[9];
+    mat3_mul_at(cam.R, vSc, tmp);
+    mat3_mul(tmp, cam.R, acc);
+#pragma unroll
+    for (int i = 0; i < 9; i++) G.vSw[i] += acc[i];
+}
+
+// Sigma = M M^T, M = R(q) diag(s)  ->  v_quat (through the normalisation), v_scale
+__device__ __forceinline__ void covar_bwd(const float Rq[9], const float s[3], const float q[4], float inv_norm,
+                                          const float vSw[9], float vq[4], float vs[3]) {
+    float M[9], vM[9], vR[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[3 * i + j] = Rq[3 * i + j] * s[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            vM[3 * i + j] = (vSw[3 * i] + vSw[i]) * M[j] + (vSw[3 * i + 1] + vSw[3 + i]) * M[3 + j] +
+                            (vSw[3 * i + 2] + vSw[6 + i]) * M[6 + j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) vs[j] = Rq[j] * vM[j] + Rq[3 + j] * vM[3 + j] + Rq[6 + j] * vM[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) vR[3 * i + j] = vM[3 * i + j] * s[j];
+    float w = q[0] * inv_norm, x = q[1] * inv_norm, y = q[2] * inv_norm, z = q[3] * inv_norm;
+    float vqn[4];
+    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+    float dq = vqn[0] * w + vqn[1] * x + vqn[2] * y + vqn[3] * z;
+    vq[0] = (vqn[0] - dq * w) * inv_norm; vq[1] = (vqn[1] - dq * x) * inv_norm;
+    vq[2] = (vqn[2] - dq * y) * inv_norm; vq[3] = (vqn[3] - dq * z) * inv_norm;
+}
+
+// copies a wave's slice of `count` floats between memory and LDS with 16-byte accesses (+ scalar tail)
+__device__ __forceinline__ void slice_load(float* lds, const float* src, int count, int lane) {
+    int n4 = count >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
+        int i4 = lane + 64 * j;
+        if (i4 < n4) l4[i4] = s4[i4];
+    }
+    int rem = count & 3;
+    if (lane < rem) lds[4 * n4 + lane] = src[4 * n4 + lane];
+}
+__device__ __forceinline__ void slice_store(float* dst, const float* lds, int count, int lane) {
+    int n4 = count >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* l4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+    for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
+        int i4 = lane + 64 * j;
+        if (i4 < n4) d4[i4] = l4[i4];
+    }
+    int rem = count & 3;
+    if (lane < rem) dst[4 * n4 + lane] = lds[4 * n4 + lane];
+}
+
+// ---- training-path backward: ONE camera, SH colours, 16-byte aligned shN / v_shN.
+// One thread per Gaussian.  The wave's shN slice comes in through LDS; each coefficient is
+// read once and its slot is overwritten in place with its gradient, then the slice leaves as
+// v_shN with 16-byte stores: no 45-float register arrays (the generic kernel needs 286 VGPRs,
+// i.e. one wave per SIMD; this one fits four).  Also accumulates the densify statistics that
+// gsplat's DefaultStrategy._update_state computes in torch.
+__global__ __launch_bounds__(256) void project_bwd1_kernel(
+    int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, const float* __restrict__ shN, int sh_degree,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, int W, int H, float eps2d, int flags,
+    const int32_t* __restrict__ radii, const float* __restrict__ splats, const float* __restrict__ v_splats,
+    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+    float* __restrict__ v_opacities, float* __restrict__ v_sh0, float* __restrict__ v_shN,
+    float* __restrict__ stat_grad2d, float* __restrict__ stat_count, float* __restrict__ stat_radii, int stat_use_abs) {
+    __shared__ float4 sSH4[4][SH_WAVE_F4];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = n_raw < N;
+    const int n = live ? n_raw : N - 1;
+    const int n0 = n_raw - lane;
+    const int count = max(0, min(64, N - n0)) * 45;          // floats in this wave's slice
+    float* const slice = reinterpret_cast<float*>(sSH4[wv]);
+    float* const my = slice + 45 * lane;
+
+    int2 rad = make_int2(0, 0);
+    if (live) rad = *reinterpret_cast<const int2*>(radii + 2 * (long long)n);
+    const bool vis = live && rad.x > 0 && rad.y > 0;
+    const bool need_coef = sh_degree >= 1 && __ballot(vis) != 0ull;
+    if (need_coef) slice_load(slice, shN + 45 * (long long)n0, count, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // same-wave LDS hand-off: ordering only
+
+    GeoGrad G;
+#pragma unroll
+    for (int i = 0; i < 3; i++) G.vmean[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) G.vSw[i] = 0.f;
+    G.vopa = 0.f;
+    float vc0[3] = {0.f, 0.f, 0.f};
+    float g2d = 0.f, cnt = 0.f, rmax = 0.f;
+    float q[4] = {1.f, 0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f}, Rq[9], inv_norm = 1.f, opa_act = 1.f;
+
+    if (vis) {
+        float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+        float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (long long)n);
+        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        s[0] = scales[3 * n]; s[1] = scales[3 * n + 1]; s[2] = scales[3 * n + 2];
+        if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
+        float opa_raw = opacities ? opacities[n] : 1.f;
+        opa_act = (flags & MI_FLAG_LOGIT_OPAC) ? sigmoidf(opa_raw) : opa_raw;
+        float Sw[9];
+        quat_to_rotmat(q, Rq, inv_norm);
+        covar_world(Rq, s, Sw);
+        const float4* vr = reinterpret_cast<const float4*>(v_splats + (long long)n * GRAD_STRIDE);
+        float4 g0 = vr[0], g1 = vr[1], g2 = vr[2];
+        float v_rgb[3] = {g1.z, g1.w, g2.x};
+        {
+            float sx = stat_use_abs ? g2.y : g0.x, sy = stat_use_abs ? g2.z : g0.y;
+            sx *= 0.5f * W; sy *= 0.5f * H;
+            g2d = sqrtf(sx * sx + sy * sy);
+            cnt = 1.f;
+            rmax = fmaxf((float)rad.x, (float)rad.y) / (float)max(W, H);
+        }
+        Cam cam = load_cam(viewmats, Ks, 0);
+        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, G);
+        // ---- colour path
+        const float4* sr = reinterpret_cast<const float4*>(splats + (long long)n * SPLAT_STRIDE);
+        float4 s1 = sr[1], s2 = sr[2];
+        if (s1.z <= 0.f) v_rgb[0] = 0.f;        // clamp(+0.5, min 0) mask
+        if (s1.w <= 0.f) v_rgb[1] = 0.f;
+        if (s2.x <= 0.f) v_rgb[2] = 0.f;
+        float cp[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) cp[i] = -(cam.R[i] * cam.t[0] + cam.R[3 + i] * cam.t[1] + cam.R[6 + i] * cam.t[2]);
+        float dx = mean[0] - cp[0], dy = mean[1] - cp[1], dz = mean[2] - cp[2];
+        float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+        float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+        float b[16], gk[16];
+        sh_basis(sh_degree, ux, uy, uz, b);
+        vc0[0] = b[0] * v_rgb[0]; vc0[1] = b[0] * v_rgb[1]; vc0[2] = b[0] * v_rgb[2];
+        gk[0] = 0.f;
+        const int nb = (sh_degree + 1) * (sh_degree + 1);
+#pragma unroll
+        for (int k = 1; k < 16; k++) {
+            if (k < nb) {
+                float c0 = my[3 * (k - 1)], c1 = my[3 * (k - 1) + 1], c2 = my[3 * (k - 1) + 2];
+                gk[k] = v_rgb[0] * c0 + v_rgb[1] * c1 + v_rgb[2] * c2;
+                my[3 * (k - 1)] = b[k] * v_rgb[0]; my[3 * (k - 1) + 1] = b[k] * v_rgb[1]; my[3 * (k - 1) + 2] = b[k] * v_rgb[2];
+            } else {
+                gk[k] = 0.f;
+                my[3 * (k - 1)] = 0.f; my[3 * (k - 1) + 1] = 0.f; my[3 * (k - 1) + 2] = 0.f;
+            }
+        }
+        float vu[3];
+        sh_basis_vjp(sh_degree, ux, uy, uz, gk, vu);
+        float dot = vu[0] * ux + vu[1] * uy + vu[2] * uz;       // normalisation vjp
+        G.vmean[0] += (vu[0] - dot * ux) * inv;
+        G.vmean[1] += (vu[1] - dot * uy) * inv;
+        G.vmean[2] += (vu[2] - dot * uz) * inv;
+    } else if (live) {
+#pragma unroll
+        for (int k = 0; k < 45; k++) my[k] = 0.f;
+    }
+    if (live) {
+        float vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            covar_bwd(Rq, s, q, inv_norm, G.vSw, vq, vs);
+            if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
+            if (flags & MI_FLAG_LOGIT_OPAC) G.vopa *= opa_act * (1.f - opa_act);
+        }
+        *reinterpret_cast<float4*>(v_quats + 4 * (long long)n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+        v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
+        v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
+        if (v_opacities) v_opacities[n] = G.vopa;
+        v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
+        if (stat_grad2d && vis) {
+            stat_grad2d[n] += g2d;
+            stat_count[n] += cnt;
+            if (stat_radii) stat_radii[n] = fmaxf(stat_radii[n], rmax);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
+}
+
+// ---- generic backward: any number of cameras, any colour mode, any alignment.  One thread per
+// Gaussian, loops over cameras and sums in registers; every output is written exactly once.
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int C, int N, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities,
@@ -303,8 +595,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     if (n >= N) return;
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
-    float sraw[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
-    float s[3] = {sraw[0], sraw[1], sraw[2]};
+    float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
     if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
     float opa_raw = opacities ? opacities[n] : 1.f;
     float opa_act = (flags & MI_FLAG_LOGIT_OPAC) ? sigmoidf(opa_raw) : opa_raw;
@@ -312,9 +603,12 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     quat_to_rotmat(q, Rq, inv_norm);
     covar_world(Rq, s, Sw);
 
-    float vmean[3] = {0.f, 0.f, 0.f};
-    float vSw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float vopa = 0.f;
+    GeoGrad G;
+#pragma unroll
+    for (int i = 0; i < 3; i++) G.vmean[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) G.vSw[i] = 0.f;
+    G.vopa = 0.f;
     float vc0[3] = {0.f, 0.f, 0.f};
     float vcN[45];
     int nb = (sh_degree + 1) * (sh_degree + 1);
@@ -333,27 +627,20 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         }
         const float4* vr = reinterpret_cast<const float4*>(v_splats + idx * GRAD_STRIDE);
         float4 g0 = vr[0], g1 = vr[1], g2 = vr[2];
-        float v_m2x = g0.x, v_m2y = g0.y, v_cA = g0.z, v_cB = g0.w, v_cC = g1.x, v_op = g1.y;
         float v_rgb[3] = {g1.z, g1.w, g2.x};
-        float v_depth = g2.w;
-        // densify statistics
         {
-            float sx = stat_use_abs ? g2.y : v_m2x, sy = stat_use_abs ? g2.z : v_m2y;
+            float sx = stat_use_abs ? g2.y : g0.x, sy = stat_use_abs ? g2.z : g0.y;
             sx *= 0.5f * W * C; sy *= 0.5f * H * C;
             g2d += sqrtf(sx * sx + sy * sy);
             cnt += 1.f;
             rmax = fmaxf(rmax, fmaxf((float)rad.x, (float)rad.y) / (float)max(W, H));
         }
         Cam cam = load_cam(viewmats, Ks, c);
-        Proj P;
-        project_core(cam, mean, Sw, W, H, eps2d, P);
-
-        // ---- colour path
+        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, G);
         if (color_mode == 0) {
             const float4* sr = reinterpret_cast<const float4*>(splats + idx * SPLAT_STRIDE);
             float4 s1 = sr[1], s2 = sr[2];
-            // clamp(+0.5, min 0) mask
-            if (s1.z <= 0.f) v_rgb[0] = 0.f;
+            if (s1.z <= 0.f) v_rgb[0] = 0.f;        // clamp(+0.5, min 0) mask
             if (s1.w <= 0.f) v_rgb[1] = 0.f;
             if (s2.x <= 0.f) v_rgb[2] = 0.f;
             float cp[3];
@@ -378,120 +665,25 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
             }
             float vu[3];
             sh_basis_vjp(sh_degree, ux, uy, uz, gk, vu);
-            // normalisation vjp: v_d = (v_u - (v_u . u) u) / |d|
-            float dot = vu[0] * ux + vu[1] * uy + vu[2] * uz;
-            vmean[0] += (vu[0] - dot * ux) * inv;
-            vmean[1] += (vu[1] - dot * uy) * inv;
-            vmean[2] += (vu[2] - dot * uz) * inv;
+            float dot = vu[0] * ux + vu[1] * uy + vu[2] * uz;   // normalisation vjp
+            G.vmean[0] += (vu[0] - dot * ux) * inv;
+            G.vmean[1] += (vu[1] - dot * uy) * inv;
+            G.vmean[2] += (vu[2] - dot * uz) * inv;
         } else if (v_colors) {
             if (color_mode == 2) { v_colors[3 * idx] = v_rgb[0]; v_colors[3 * idx + 1] = v_rgb[1]; v_colors[3 * idx + 2] = v_rgb[2]; }
             else { vc0[0] += v_rgb[0]; vc0[1] += v_rgb[1]; vc0[2] += v_rgb[2]; }
         }
-
-        // ---- opacity / compensation
-        float vcov_a = 0.f, vcov_b = 0.f, vcov_c = 0.f;   // symmetric 2x2 grad: [[a, b],[b, c]]
-        if (flags & MI_FLAG_ANTIALIASED) {
-            vopa += v_op * P.comp;
-            float v_comp = v_op * opa_act;
-            float det_conic = P.conA * P.conC - P.conB * P.conB;
-            float v_sqr = v_comp * 0.5f / (P.comp + 1e-6f);
-            float om = 1.f - P.comp * P.comp;
-            vcov_a += v_sqr * (om * P.conA - eps2d * det_conic);
-            vcov_b += v_sqr * (om * P.conB);
-            vcov_c += v_sqr * (om * P.conC - eps2d * det_conic);
-        } else {
-            vopa += v_op;
-        }
-        // ---- conic = inverse(cov2d): G_cov = -X G_X X, G_X = [[vA, vB/2],[vB/2, vC]]
-        {
-            float xa = P.conA, xb = P.conB, xc = P.conC;
-            float ga = v_cA, gb = 0.5f * v_cB, gc = v_cC;
-            // T = X G
-            float t00 = xa * ga + xb * gb, t01 = xa * gb + xb * gc;
-            float t10 = xb * ga + xc * gb, t11 = xb * gb + xc * gc;
-            vcov_a -= t00 * xa + t01 * xb;
-            vcov_b -= t00 * xb + t01 * xc;
-            vcov_c -= t10 * xb + t11 * xc;
-        }
-        // ---- cov2d = J Sc J^T ; mean2d
-        float G[4] = {vcov_a, vcov_b, vcov_b, vcov_c};
-        float vSc[9];
-        // v_Sc = J^T G J
-        {
-            float GJ[6];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) GJ[3 * i + j] = G[2 * i] * P.J[j] + G[2 * i + 1] * P.J[3 + j];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) vSc[3 * i + j] = P.J[i] * GJ[j] + P.J[3 + i] * GJ[3 + j];
-            // v_J = 2 G J Sc  (G, Sc symmetric)
-            float vJ[6];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    vJ[3 * i + j] = 2.f * (GJ[3 * i] * P.Sc[j] + GJ[3 * i + 1] * P.Sc[3 + j] + GJ[3 * i + 2] * P.Sc[6 + j]);
-            float x = P.mc[0], y = P.mc[1], z = P.mc[2];
-            float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
-            float vmc[3];
-            vmc[0] = cam.fx * rz * v_m2x;
-            vmc[1] = cam.fy * rz * v_m2y;
-            vmc[2] = -(cam.fx * x * v_m2x + cam.fy * y * v_m2y) * rz2 + v_depth;
-            if (P.x_in) vmc[0] += -cam.fx * rz2 * vJ[2];
-            else vmc[2] += -cam.fx * rz3 * vJ[2] * P.tx;
-            if (P.y_in) vmc[1] += -cam.fy * rz2 * vJ[5];
-            else vmc[2] += -cam.fy * rz3 * vJ[5] * P.ty;
-            vmc[2] += -cam.fx * rz2 * vJ[0] - cam.fy * rz2 * vJ[4] + 2.f * cam.fx * P.tx * rz3 * vJ[2] +
-                      2.f * cam.fy * P.ty * rz3 * vJ[5];
-            // world: v_mean += R^T v_mc ; v_Sw += R^T v_Sc R
-#pragma unroll
-            for (int i = 0; i < 3; i++) vmean[i] += cam.R[i] * vmc[0] + cam.R[3 + i] * vmc[1] + cam.R[6 + i] * vmc[2];
-            float tmp[9], acc[9];
-            mat3_mul_at(cam.R, vSc, tmp);
-            mat3_mul(tmp, cam.R, acc);
-#pragma unroll
-            for (int i = 0; i < 9; i++) vSw[i] += acc[i];
-        }
     }
-
-    // ---- Sigma = M M^T, M = R diag(s): v_M = (v_S + v_S^T) M
-    float M[9], vM[9];
+    float vq[4], vs[3];
+    covar_bwd(Rq, s, q, inv_norm, G.vSw, vq, vs);
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) M[3 * i + j] = Rq[3 * i + j] * s[j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            vM[3 * i + j] = (vSw[3 * i] + vSw[i]) * M[j] + (vSw[3 * i + 1] + vSw[3 + i]) * M[3 + j] +
-                            (vSw[3 * i + 2] + vSw[6 + i]) * M[6 + j];
-    float vs[3], vR[9];
-#pragma unroll
-    for (int j = 0; j < 3; j++) vs[j] = Rq[j] * vM[j] + Rq[3 + j] * vM[3 + j] + Rq[6 + j] * vM[6 + j];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) vR[3 * i + j] = vM[3 * i + j] * s[j];
-    float w = q[0] * inv_norm, x = q[1] * inv_norm, y = q[2] * inv_norm, z = q[3] * inv_norm;
-    float vqn[4];
-    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
-    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
-    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
-    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
-    float dq = vqn[0] * w + vqn[1] * x + vqn[2] * y + vqn[3] * z;
-    float qn[4] = {w, x, y, z};
-#pragma unroll
-    for (int i = 0; i < 4; i++) v_quats[4 * n + i] = (vqn[i] - dq * qn[i]) * inv_norm;
+    for (int i = 0; i < 4; i++) v_quats[4 * n + i] = vq[i];
     if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
     v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
-    v_means[3 * n] = vmean[0]; v_means[3 * n + 1] = vmean[1]; v_means[3 * n + 2] = vmean[2];
+    v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
     if (v_opacities) {
-        if (flags & MI_FLAG_LOGIT_OPAC) vopa *= opa_act * (1.f - opa_act);
-        v_opacities[n] = vopa;
+        if (flags & MI_FLAG_LOGIT_OPAC) G.vopa *= opa_act * (1.f - opa_act);
+        v_opacities[n] = G.vopa;
     }
     if (color_mode == 0) {
         v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
@@ -542,10 +734,18 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
     MI_REQUIRE(v_means && v_quats && v_scales, "project_bwd: v_means/v_quats/v_scales required");
     MI_REQUIRE(color_mode != 0 || (v_sh0 && v_shN), "project_bwd: SH mode needs v_sh0/v_shN");
     if (N == 0) return 0;
-    MI_LAUNCH("project_bwd", project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
-                       quats, scales, opacities, sh0, shN, color_mode, sh_degree, viewmats, Ks, width, height, eps2d,
-                       flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_colors,
-                       stat_grad2d, stat_count, stat_radii, stat_use_abs);
+    const bool fast = C == 1 && color_mode == 0 && ((((uintptr_t)shN) | ((uintptr_t)v_shN) | ((uintptr_t)quats) |
+                                                     ((uintptr_t)v_quats)) & 15) == 0;
+    if (fast)
+        MI_LAUNCH("project_bwd", project_bwd1_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means,
+                  quats, scales, opacities, shN, sh_degree, viewmats, Ks, width, height, eps2d, flags, radii, splats,
+                  v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, stat_grad2d, stat_count, stat_radii,
+                  stat_use_abs);
+    else
+        MI_LAUNCH("project_bwd", project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N,
+                  means, quats, scales, opacities, sh0, shN, color_mode, sh_degree, viewmats, Ks, width, height, eps2d,
+                  flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_colors,
+                  stat_grad2d, stat_count, stat_radii, stat_use_abs);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -168,9 +168,13 @@ def test_rasterization_forward_matches_oracle(dev, mode, bg, sh_degree):
     assert a_ref.max() > 0.5      # the scene is not trivially empty
 
 
-@pytest.mark.parametrize("mode,bg,sh_degree", [("classic", True, 3), ("antialiased", False, 3), ("classic", True, 0)])
-def test_rasterization_backward_matches_autograd_oracle(dev, mode, bg, sh_degree):
-    sc = small_scene(n=350, seed=8, big=True, width=64, height=48)
+@pytest.mark.parametrize("mode,bg,sh_degree,n_views,n", [
+    ("classic", True, 3, 2, 350), ("antialiased", False, 3, 2, 350), ("classic", True, 0, 2, 350),
+    # one camera = the training path's dedicated project_bwd kernel (LDS-staged shN slices);
+    # 350 and 64 exercise the partial last wave and the exactly-full wave
+    ("classic", True, 3, 1, 350), ("antialiased", True, 2, 1, 64), ("classic", False, 1, 1, 333), ("classic", True, 0, 1, 130)])
+def test_rasterization_backward_matches_autograd_oracle(dev, mode, bg, sh_degree, n_views, n):
+    sc = small_scene(n=n, seed=8, big=True, width=64, height=48, n_views=n_views)
     (r_ref, a_ref, _, leaves), (r, a, _, gl) = _run_both(sc, dev, sh_degree, bg, mode)
     gen = torch.Generator().manual_seed(2)
     wr = torch.randn(r_ref.shape, generator=gen).double()
