@@ -30,6 +30,8 @@ struct AdamArgs {
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int AD_THREADS = 256;
 constexpr int AD_PER_BLOCK = AD_THREADS * 4 * 4;   // 4 float4 per thread
 
@@ -57,17 +59,20 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, 
         long long i = base + ((long long)it * AD_THREADS + threadIdx.x) * 4;
         if (i >= sg.n) break;
         if (aligned && i + 4 <= sg.n) {
-            float4 p = *reinterpret_cast<float4*>(sg.p + i);
-            float4 g = *reinterpret_cast<const float4*>(sg.g + i);
-            float4 m = *reinterpret_cast<float4*>(sg.m + i);
-            float4 v = *reinterpret_cast<float4*>(sg.v + i);
-            adam1(p.x, g.x, m.x, v.x, step_size, b1, b2, inv_bc2_sqrt, eps);
-            adam1(p.y, g.y, m.y, v.y, step_size, b1, b2, inv_bc2_sqrt, eps);
-            adam1(p.z, g.z, m.z, v.z, step_size, b1, b2, inv_bc2_sqrt, eps);
-            adam1(p.w, g.w, m.w, v.w, step_size, b1, b2, inv_bc2_sqrt, eps);
-            *reinterpret_cast<float4*>(sg.p + i) = p;
-            *reinterpret_cast<float4*>(sg.m + i) = m;
-            *reinterpret_cast<float4*>(sg.v + i) = v;
+            // streamed once per step, never re-read before the next step: non-temporal
+            f32x4 p = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.p + i));
+            f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.g + i));
+            f32x4 m = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.m + i));
+            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.v + i));
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float pe = p[e], me = m[e], ve = v[e];
+                adam1(pe, g[e], me, ve, step_size, b1, b2, inv_bc2_sqrt, eps);
+                p[e] = pe; m[e] = me; v[e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(sg.p + i) = p;         // parameters are re-read by the next forward
+            __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(sg.m + i));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(sg.v + i));
         } else {
             for (int k = 0; k < 4 && i + k < sg.n; k++) {
                 float p = sg.p[i + k], m = sg.m[i + k], v = sg.v[i + k];
