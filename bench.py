@@ -311,15 +311,36 @@ def main():
                     e["alg_bytes_per_launch"] = alg[tag]
                     e["alg_GBps"] = alg[tag] / (ms / cnt * 1e-3) / 1e9
                 stages[tag] = e
+            # pixel-splat pairs any implementation has to evaluate: every list entry up to the last
+            # contributor of each pixel (SURVEY.md 8d "algorithmic flops": 20 / 60 flop per pair)
+            lb = tr.last_binning
+            lid = tr.raster_out["last_ids"][0].long()
+            al = tr.raster_out["alphas"][0, ..., 0]
+            offs = lb["isect_offsets"][0].long()
+            tstart = offs.repeat_interleave(16, 0).repeat_interleave(16, 1)[: sc.height, : sc.width]
+            pairs = int(((lid - tstart + 1) * (al > 0)).sum().item())
+            flop = {"rasterize_fwd": 20.0 * pairs, "rasterize_bwd": 60.0 * pairs}
+            for k, f in flop.items():
+                if k in stages:
+                    stages[k]["alg_flop_per_launch"] = f
+                    stages[k]["alg_TFLOPs"] = f / (stages[k]["us_per_launch"] * 1e-6) / 1e12
             dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["ms_per_step"])
-            ach = stages[dom]["alg_GBps"]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured offline with rocprofv3 --pmc
             if os.path.isfile(pmc):
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=traffic, us_per_launch=stages[dom]["us_per_launch"],
-                        alg_bytes_per_launch=alg[dom], launches_per_step=stages[dom]["launches_per_step"])
+            common = dict(kernel=dom, traffic=traffic, us_per_launch=stages[dom]["us_per_launch"],
+                          launches_per_step=stages[dom]["launches_per_step"], alg_bytes_per_launch=alg[dom],
+                          alg_GBps=stages[dom]["alg_GBps"], hbm_frac=stages[dom]["alg_GBps"] / HBM_PEAK_GBS)
+            if dom in flop:
+                # the rasteriser is bound by vector issue, not HBM (its gathers hit L2/MALL): price it
+                # against the f32 matrix/vector pipe peak (f32 MFMA rate == f32 VALU rate on gfx950)
+                ach = stages[dom]["alg_TFLOPs"]
+                roof = dict(bound="mfma", achieved=ach, peak=F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / F32_PEAK_TFLOPS,
+                            pairs=pairs, **common)
+            else:
+                ach = stages[dom]["alg_GBps"]
+                roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, **common)
         cpu = None
         log("stage profile done; cpu baseline")
         if not args.no_cpu_baseline:
