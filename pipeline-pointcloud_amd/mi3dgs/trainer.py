@@ -238,9 +238,11 @@ class Trainer:
                       int(do_grow), int(self.step_count > c.reset_every), ops._p(flags), ops._p(counts), st)
         ops.scan_exclusive_u32(counts, offs, self.total_buf)
         new_n = int(self.total_buf.item())
+        if new_n > m.capacity and do_grow:
+            # out of room: this pass only prunes (upstream has no cap; ours is TrainConfig.capacity)
+            return self.refine(do_grow=False)
         if new_n > m.capacity:
-            raise RuntimeError(f"densify would create {new_n} Gaussians but capacity is {m.capacity}; "
-                               "raise TrainConfig.capacity")
+            raise RuntimeError(f"refine would keep {new_n} Gaussians but capacity is {m.capacity}")
         src, dst = m.banks[m.cur], m.banks[1 - m.cur]
         seed = (self.cfg.seed * 1000003 + self.step_count * 7919 + 12345) & 0xFFFFFFFF
         ops._lib.call("mi3dgs_densify_scatter", n,
