@@ -93,15 +93,21 @@ int mi3dgs_project_bwd(int C, int N, const float* means, const float* quats, con
  * allocation) or skip the read-back and size flatten_ids / tile_keys by capacity
  * (`max_isect`): every kernel takes its live count from n_isect_dev[0] on the device. */
 size_t mi3dgs_bin_workspace_bytes(int C, int N, long long max_isect);
+/* `tight` = 0: bin by the splat's bounding box, exactly gsplat's tile lists (flatten_ids,
+ * isect_ids, tiles_per_gauss identical to upstream).  `tight` = 1: per tile row keep only the
+ * span the ellipse sigma <= ln(255 opacity) reaches -- renders and gradients are bit-identical
+ * (the dropped pairs fail the rasteriser's alpha >= 1/255 test on every pixel), the lists are
+ * shorter.  `height` is the image height in pixels.  Both phases must use the same value. */
 int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float* splats, int tile_size,
-                     int tile_width, int tile_height, int32_t* tiles_per_gauss /* [C*N], nullable */,
-                     int32_t* n_isect_dev /* [1] */, void* workspace, size_t workspace_bytes,
-                     long long max_isect, void* stream);
+                     int tile_width, int tile_height, int height, int tight,
+                     int32_t* tiles_per_gauss /* [C*N], nullable */, int32_t* n_isect_dev /* [1] */,
+                     void* workspace, size_t workspace_bytes, long long max_isect, void* stream);
 /* flatten_ids[max_isect] (index into the C*N records, sorted by (camera, tile, depth)),
  * tile_keys[max_isect] (camera*tiles + tile), isect_offsets[C*tile_height*tile_width],
  * isect_ids_opt[max_isect] int64 (nullable): gsplat's (tile << 32 | depth bits) keys. */
 int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int tile_size,
-                    int tile_width, int tile_height, const int32_t* n_isect_dev, long long max_isect,
+                    int tile_width, int tile_height, int height, int tight,
+                    const int32_t* n_isect_dev, long long max_isect,
                     int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
                     int64_t* isect_ids_opt, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -407,3 +407,27 @@ def strategy_masks(state: Dict, scales_exp: torch.Tensor, opacities_sig: torch.T
     if step > reset_every:
         is_prune = is_prune | (scales_exp.amax(-1) > prune_scale3d * scene_scale)
     return is_dupli, is_split, is_prune
+
+
+# ------------------------------------------------------- exact contributing (tile, splat) set
+def contributing_pairs(means2d, conics, opacities, radii, width: int, height: int, tile_size: int = 16):
+    """Brute force, float64: the set of (camera, tile, Gaussian) triples in which at least one
+    pixel centre of the tile receives alpha = o exp(-sigma) >= 1/255 from the Gaussian.  Any
+    binning scheme has to keep at least these; gsplat's bounding-box binning keeps more.
+    Returns a sorted int64 tensor of codes ((cam * n_tiles + tile) * N + gaussian)."""
+    C, N = opacities.shape
+    tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float64) + 0.5,
+                            torch.arange(width, dtype=torch.float64) + 0.5, indexing="ij")
+    tile_of_px = ((ys.long() // tile_size) * tw + (xs.long() // tile_size)).flatten()
+    out = []
+    for c in range(C):
+        for g in torch.nonzero((radii[c] > 0).all(-1)).flatten().tolist():
+            dx = means2d[c, g, 0].double() - xs.flatten()
+            dy = means2d[c, g, 1].double() - ys.flatten()
+            A, B, Cc = conics[c, g].double()
+            sigma = 0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy
+            hit = (sigma >= 0) & (opacities[c, g].double() * torch.exp(-sigma) >= ALPHA_THRESHOLD)
+            tiles = torch.unique(tile_of_px[hit])
+            out.append((c * tw * th + tiles) * N + g)
+    return torch.sort(torch.cat(out)).values if out else torch.zeros(0, dtype=torch.int64)

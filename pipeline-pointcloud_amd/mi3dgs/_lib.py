@@ -34,8 +34,8 @@ _SIGNATURES = {
     "mi3dgs_project_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
                                 _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "mi3dgs_bin_workspace_bytes": (_sz, [_i, _i, _ll]),
-    "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
-    "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),
+    "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
+    "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),
     "mi3dgs_sort_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),

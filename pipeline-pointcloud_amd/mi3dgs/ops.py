@@ -123,8 +123,10 @@ def project_bwd(means, quats, scales, opacities, viewmats, Ks, width, height, ra
 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
-              want_isect_ids: bool = False, want_tiles_per_gauss: bool = False):
-    """Tile binning.  With max_isect=None the intersection count is read back (one host
+              want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False):
+    """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops
+    the (tile, splat) pairs the ellipse sigma <= ln(255 o) cannot reach (identical renders and
+    gradients, fewer intersections).  With max_isect=None the intersection count is read back (one host
     sync) and the outputs are sized exactly; otherwise outputs hold max_isect entries and
     the live count stays on the device (no sync)."""
     Cn, N = radii.shape[0], radii.shape[1]
@@ -138,8 +140,8 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     ws_bytes = _lib.lib().mi3dgs_bin_workspace_bytes(Cn, N, cap)
     ws = workspace(ws_bytes, dev)
     st = _stream(dev)
-    _lib.call("mi3dgs_bin_count", Cn, N, _p(radii), _p(splats), tile_size, tw, th, _p(tpg), _p(n_isect), _p(ws),
-              ws.numel(), cap, st)
+    _lib.call("mi3dgs_bin_count", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+              _p(tpg), _p(n_isect), _p(ws), ws.numel(), cap, st)
     if not cap_known:
         cap = int(n_isect.item())
         ws_bytes = _lib.lib().mi3dgs_bin_workspace_bytes(Cn, N, cap)
@@ -153,7 +155,8 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     tile_keys = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
     offsets = torch.empty(Cn, th, tw, dtype=torch.int32, device=dev)
     isect_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
-    _lib.call("mi3dgs_bin_emit", Cn, N, _p(radii), _p(splats), tile_size, tw, th, _p(n_isect), cap, _p(flatten_ids),
+    _lib.call("mi3dgs_bin_emit", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+              _p(n_isect), cap, _p(flatten_ids),
               _p(tile_keys), _p(offsets), _p(isect_ids), _p(ws), ws.numel(), st)
     out = dict(n_isect=n_isect, flatten_ids=flatten_ids[:cap] if not cap_known else flatten_ids,
                tile_keys=tile_keys[:cap] if not cap_known else tile_keys, isect_offsets=offsets,

@@ -67,6 +67,8 @@ class TrainConfig:
     # count back every step and allocate exactly; an int = no host sync in the step)
     capacity: Optional[int] = None
     max_isect: Optional[int] = None
+    # exact ellipse-tile culling at binning time (identical renders/gradients, fewer intersections)
+    tight_tiles: bool = True
     seed: int = 0
 
 
@@ -160,7 +162,7 @@ class Trainer:
         ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats)
-        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect)
+        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids

@@ -339,3 +339,58 @@ def test_training_recovers_target(dev):
         tr.step(i % 4)
     last = sum(tr.step(i % 4, want_loss=True) for i in range(4)) / 4
     assert last < 0.5 * first, (first, last)
+
+
+# ------------------------------------------------------------- exact ("tight") tile culling
+@pytest.mark.parametrize("seed,big", [(41, True), (42, False), (43, True)])
+def test_tight_binning_is_conservative_and_renders_bit_identical(dev, seed, big):
+    ops = _ops()
+    sc = small_scene(n=900, seed=seed, big=big, n_views=2, width=112, height=72)
+    # elongated splats at odd angles are the interesting case for an ellipse-vs-tile test
+    sc.params["scales"][:300, 0] += 1.5
+    sc.params["scales"][:300, 1] -= 1.0
+    g = sc.to(dev)
+    radii, splats = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                                    g.viewmats, g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"],
+                                    sh_degree=3, flags=3)
+    box = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, want_tiles_per_gauss=True)
+    tight = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, want_tiles_per_gauss=True, tight=True)
+    N = 900
+
+    def codes(b):
+        return torch.sort(b["tile_keys"].long().cpu() * N + (b["flatten_ids"].long().cpu() % N)
+                          + 0 * b["flatten_ids"].long().cpu()).values
+
+    def pair_codes(b):
+        fid = b["flatten_ids"].long().cpu()
+        return torch.sort(b["tile_keys"].long().cpu() * N + fid % N).values
+
+    sp = splats.cpu()
+    need = O.contributing_pairs(sp[..., 0:2], sp[..., 2:5], sp[..., 5], radii.cpu(), sc.width, sc.height)
+    cb, ct = pair_codes(box), pair_codes(tight)
+    n_box, n_tight = cb.numel(), ct.numel()
+    assert n_tight < n_box and need.numel() <= n_tight
+    assert torch.isin(need, ct).all(), "tight binning dropped a contributing (tile, splat) pair"
+    assert torch.isin(ct, cb).all(), "tight binning invented a pair outside the bounding box"
+    assert int(tight["n_isect"].item()) == n_tight == int(tight["tiles_per_gauss"].sum())
+    # per-tile lists stay depth-ordered and the offsets are consistent
+    tk = tight["tile_keys"].long().cpu()
+    assert (tk[1:] >= tk[:-1]).all()
+    offs = tight["isect_offsets"].flatten().long().cpu()
+    assert torch.equal(offs, torch.searchsorted(tk, torch.arange(offs.numel())))
+    dep = sp[..., 9].flatten()[tight["flatten_ids"].long().cpu()]
+    same_tile = tk[1:] == tk[:-1]
+    assert (dep[1:][same_tile] >= dep[:-1][same_tile]).all()
+    # renders: bit for bit
+    bg = torch.rand(2, 3, device=dev)
+    r0, a0, l0 = [t.clone() for t in ops.rasterize_fwd(splats, box, sc.width, sc.height, 16, bg)]
+    r1, a1, l1 = ops.rasterize_fwd(splats, tight, sc.width, sc.height, 16, bg)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    # gradients: same sums (float atomics order differs), so compare closely
+    gen = torch.Generator().manual_seed(1)
+    vr = torch.randn(r0.shape, generator=gen).to(dev)
+    va = torch.randn(a0.shape, generator=gen).to(dev)
+    g0 = ops.rasterize_bwd(splats, box, sc.width, sc.height, a0, l0, vr, va, 16, bg)
+    g1 = ops.rasterize_bwd(splats, tight, sc.width, sc.height, a1, l1, vr, va, 16, bg)
+    assert rel_err(g1, g0) < 1e-5
+    print(f"intersections: box {n_box}, tight {n_tight} ({100.0 * n_tight / n_box:.0f} %), exact {need.numel()}")
