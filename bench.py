@@ -304,6 +304,9 @@ def main():
                 "rasterize_bwd": I * 80 + Px * 32,
                 "project_bwd": n * 44 + n_vis * (192 + 64 + 64) + n * 236,
                 "adam": n * 1652,
+                # fused backward + Adam: read p, m, v (708) and write them (708) for every Gaussian, plus
+                # radii (8) and, for the visible ones, the splat and gradient records (128)
+                "project_bwd_adam": n * (708 + 708 + 8) + n_vis * 128,
             }
             for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 e = dict(ms_per_step=ms / iters, launches_per_step=cnt / iters, us_per_launch=1e3 * ms / cnt)

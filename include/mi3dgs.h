@@ -87,6 +87,23 @@ int mi3dgs_project_bwd(int C, int N, const float* means, const float* quats, con
                        float* v_colors /* nullable */, float* stat_grad2d, float* stat_count,
                        float* stat_radii, int stat_use_abs, void* stream);
 
+/* The same backward for the training path (ONE camera, SH colours) with the Adam step -- and,
+ * when scale_reg_weight > 0, the splatfacto scale regulariser (reference main.py:1288) -- fused
+ * in: the six parameter arrays are updated IN PLACE and no gradient array is written, which
+ * removes the 944-byte-per-Gaussian gradient round trip of a separate mi3dgs_adam_step.
+ * exp_avg / exp_avg_sq / lrs are HOST arrays of 6 in the group order means[3], quats[4],
+ * scales[3], opacities[1], sh0[3], shN[45]; `step` is 1-based.  quats, shN and the shN
+ * moments must be 16-byte aligned.  Not for the data-parallel mode (gradients must be
+ * all-reduced first): use mi3dgs_project_bwd + mi3dgs_adam_step there. */
+int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float* scales, float* opacities,
+                            float* sh0, float* shN, int sh_degree, const float* viewmats,
+                            const float* Ks, int width, int height, float eps2d, int flags,
+                            const int32_t* radii, const float* splats, const float* v_splats,
+                            float* const* exp_avg, float* const* exp_avg_sq, const float* lrs,
+                            int step, float beta1, float beta2, float eps, float scale_reg_weight,
+                            float scale_reg_max_ratio, float* stat_grad2d, float* stat_count,
+                            float* stat_radii, int stat_use_abs, void* stream);
+
 /* ---- tile binning --------------------------------------------------------------------
  * Replaces gsplat isect_tiles (count + emit + cub radix sort) and isect_offset_encode.
  * Two phases so that the caller may read the intersection count back between them (exact

@@ -171,4 +171,13 @@ __device__ __forceinline__ unsigned wave_sum_all_u32(unsigned v) {
     return v;
 }
 
+// One Adam update (torch.optim.Adam semantics): shared by optim.hip and the fused backward.
+__device__ __forceinline__ void mi_adam1(float& p, float g, float& m, float& v, float step_size, float b1, float b2,
+                                         float inv_bc2_sqrt, float eps) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p -= step_size * m / denom;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -35,13 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int AD_THREADS = 256;
 constexpr int AD_PER_BLOCK = AD_THREADS * 4 * 4;   // 4 float4 per thread
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float step_size, float b1, float b2,
-                                      float inv_bc2_sqrt, float eps) {
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-    p -= step_size * m / denom;
-}
+#define adam1 mi_adam1
 
 __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, float b2, float eps, float inv_bc1,
                                                           float inv_bc2_sqrt) {

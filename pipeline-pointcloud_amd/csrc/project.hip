@@ -11,6 +11,7 @@
 // 44 B (+192 B SH when visible) read + 72 B written per visible Gaussian; backward
 // 236 + 64 B read, 236 B written.
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -460,9 +461,25 @@ __device__ __forceinline__ void slice_store(float* dst, const float* lds, int co
 // v_shN with 16-byte stores: no 45-float register arrays (the generic kernel needs 286 VGPRs,
 // i.e. one wave per SIMD; this one fits four).  Also accumulates the densify statistics that
 // gsplat's DefaultStrategy._update_state computes in torch.
+//
+// FUSE = true additionally applies the Adam step (and, when asked, the splatfacto scale
+// regulariser) to this Gaussian's 59 parameters right here, where its gradients already sit in
+// registers / in the LDS slice: the 944 MB per step that a separate Adam launch spends on
+// writing and re-reading the gradients disappear, and the shN group (76 % of all parameters)
+// is updated with whole-wave 16-byte accesses.  Parameters are then read and written through
+// the same pointers, hence no __restrict__ on them.
+struct FusedAdam {
+    float* m[6];            // means, quats, scales, opacities, sh0, shN
+    float* v[6];
+    float* sh0;             // parameter itself (the backward does not otherwise read it)
+    float step_size[6];     // lr / (1 - beta1^t)
+    float b1, b2, eps, inv_bc2_sqrt;
+    float sreg_weight, sreg_max_ratio;   // scale regulariser of this step, weight 0 = off
+};
+
+template <bool FUSE>
 __global__ __launch_bounds__(256) void project_bwd1_kernel(
-    int N, const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
-    const float* __restrict__ opacities, const float* __restrict__ shN, int sh_degree,
+    int N, float* means, float* quats, float* scales, float* opacities, float* shN, int sh_degree, FusedAdam A,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int W, int H, float eps2d, int flags,
     const int32_t* __restrict__ radii, const float* __restrict__ splats, const float* __restrict__ v_splats,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
@@ -563,19 +580,82 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
             if (flags & MI_FLAG_LOGIT_OPAC) G.vopa *= opa_act * (1.f - opa_act);
         }
-        *reinterpret_cast<float4*>(v_quats + 4 * (long long)n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
-        v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
-        v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
-        if (v_opacities) v_opacities[n] = G.vopa;
-        v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
         if (stat_grad2d && vis) {
             stat_grad2d[n] += g2d;
             stat_count[n] += cnt;
             if (stat_radii) stat_radii[n] = fmaxf(stat_radii[n], rmax);
         }
+        if (!FUSE) {
+            *reinterpret_cast<float4*>(v_quats + 4 * (long long)n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
+            v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
+            if (v_opacities) v_opacities[n] = G.vopa;
+            v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
+        } else {
+            // ---- Adam on the five small groups, one thread per Gaussian
+            float sl[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+            if (A.sreg_weight > 0.f) {
+                // splatfacto use_scale_regularization: weight * mean(max(ratio, max_ratio) - max_ratio)
+                float mx = fmaxf(sl[0], fmaxf(sl[1], sl[2])), mn = fminf(sl[0], fminf(sl[1], sl[2]));
+                float ratio = __expf(mx - mn);
+                if (ratio > A.sreg_max_ratio) {
+                    float gg = A.sreg_weight * ratio / (float)N;
+                    int nmx = (sl[0] == mx) + (sl[1] == mx) + (sl[2] == mx);
+                    int nmn = (sl[0] == mn) + (sl[1] == mn) + (sl[2] == mn);
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        vs[i] += (sl[i] == mx ? gg / (float)nmx : 0.f) - (sl[i] == mn ? gg / (float)nmn : 0.f);
+                }
+            }
+#define MI_ADAM_ROW(GRP, PTR, W, GRADS)                                                                      \
+            {                                                                                                \
+                _Pragma("unroll") for (int i = 0; i < (W); i++) {                                            \
+                    long long o = (long long)(W) * n + i;                                                    \
+                    float pp = (PTR)[o], mm = A.m[GRP][o], vv = A.v[GRP][o];                                 \
+                    mi_adam1(pp, (GRADS)[i], mm, vv, A.step_size[GRP], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);   \
+                    (PTR)[o] = pp; A.m[GRP][o] = mm; A.v[GRP][o] = vv;                                       \
+                }                                                                                            \
+            }
+            float gop[1] = {G.vopa};
+            MI_ADAM_ROW(0, means, 3, G.vmean)
+            MI_ADAM_ROW(1, quats, 4, vq)
+            MI_ADAM_ROW(2, scales, 3, vs)
+            if (opacities) MI_ADAM_ROW(3, opacities, 1, gop)
+            MI_ADAM_ROW(4, A.sh0, 3, vc0)
+#undef MI_ADAM_ROW
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
+    if (!FUSE) {
+        slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
+    } else {
+        // ---- Adam on the wave's shN slice: gradients from LDS, p / m / v streamed with 16-byte accesses
+        const long long off = 45 * (long long)n0;
+        const int n4 = count >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(slice);
+        float4* p4 = reinterpret_cast<float4*>(shN + off);
+        float4* m4 = reinterpret_cast<float4*>(A.m[5] + off);
+        float4* v4 = reinterpret_cast<float4*>(A.v[5] + off);
+#pragma unroll
+        for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
+            int i4 = lane + 64 * j;
+            if (i4 < n4) {
+                float4 g = g4[i4], pp = p4[i4], mm = m4[i4], vv = v4[i4];
+                mi_adam1(pp.x, g.x, mm.x, vv.x, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                mi_adam1(pp.y, g.y, mm.y, vv.y, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                mi_adam1(pp.z, g.z, mm.z, vv.z, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                mi_adam1(pp.w, g.w, mm.w, vv.w, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                p4[i4] = pp; m4[i4] = mm; v4[i4] = vv;
+            }
+        }
+        int rem = count & 3;
+        if (lane < rem) {
+            long long o = off + 4 * n4 + lane;
+            float pp = shN[o], mm = A.m[5][o], vv = A.v[5][o];
+            mi_adam1(pp, slice[4 * n4 + lane], mm, vv, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            shN[o] = pp; A.m[5][o] = mm; A.v[5][o] = vv;
+        }
+    }
 }
 
 // ---- generic backward: any number of cameras, any colour mode, any alignment.  One thread per
@@ -736,16 +816,54 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
     if (N == 0) return 0;
     const bool fast = C == 1 && color_mode == 0 && ((((uintptr_t)shN) | ((uintptr_t)v_shN) | ((uintptr_t)quats) |
                                                      ((uintptr_t)v_quats)) & 15) == 0;
-    if (fast)
-        MI_LAUNCH("project_bwd", project_bwd1_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means,
-                  quats, scales, opacities, shN, sh_degree, viewmats, Ks, width, height, eps2d, flags, radii, splats,
-                  v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, stat_grad2d, stat_count, stat_radii,
-                  stat_use_abs);
+    if (fast) {
+        FusedAdam none = {};
+        MI_LAUNCH("project_bwd", project_bwd1_kernel<false>, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                  const_cast<float*>(means), const_cast<float*>(quats), const_cast<float*>(scales),
+                  const_cast<float*>(opacities), const_cast<float*>(shN), sh_degree, none, viewmats, Ks, width, height,
+                  eps2d, flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN,
+                  stat_grad2d, stat_count, stat_radii, stat_use_abs);
+    }
     else
         MI_LAUNCH("project_bwd", project_bwd_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, C, N,
                   means, quats, scales, opacities, sh0, shN, color_mode, sh_degree, viewmats, Ks, width, height, eps2d,
                   flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_colors,
                   stat_grad2d, stat_count, stat_radii, stat_use_abs);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// Single-camera SH backward with the Adam step fused in (see project_bwd1_kernel).  The parameter
+// arrays are updated IN PLACE; no gradient is written.  exp_avg / exp_avg_sq / lrs follow the
+// group order means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45] (HOST arrays of 6).
+// scale_reg_weight > 0 adds the splatfacto scale regulariser's gradient for this step.
+extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float* scales, float* opacities, float* sh0,
+                                       float* shN, int sh_degree, const float* viewmats, const float* Ks, int width,
+                                       int height, float eps2d, int flags, const int32_t* radii, const float* splats,
+                                       const float* v_splats, float* const* exp_avg, float* const* exp_avg_sq,
+                                       const float* lrs, int step, float beta1, float beta2, float eps,
+                                       float scale_reg_weight, float scale_reg_max_ratio, float* stat_grad2d,
+                                       float* stat_count, float* stat_radii, int stat_use_abs, void* stream) {
+    MI_REQUIRE(N >= 0 && step >= 1, "project_bwd_adam: bad N / step (step is 1-based)");
+    MI_REQUIRE(means && quats && scales && sh0 && shN && exp_avg && exp_avg_sq && lrs, "project_bwd_adam: null argument");
+    if (N == 0) return 0;
+    FusedAdam A;
+    uintptr_t align = ((uintptr_t)shN) | ((uintptr_t)quats);
+    for (int g = 0; g < 6; g++) {
+        A.m[g] = exp_avg[g]; A.v[g] = exp_avg_sq[g];
+        MI_REQUIRE(A.m[g] && A.v[g], "project_bwd_adam: null Adam moment buffer");
+    }
+    align |= ((uintptr_t)A.m[5]) | ((uintptr_t)A.v[5]);
+    MI_REQUIRE((align & 15) == 0, "project_bwd_adam: quats, shN and the shN moments must be 16-byte aligned");
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int g = 0; g < 6; g++) A.step_size[g] = (float)(lrs[g] / bc1);
+    A.sh0 = sh0;
+    A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
+    MI_LAUNCH("project_bwd_adam", project_bwd1_kernel<true>, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+              means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height, eps2d, flags, radii, splats,
+              v_splats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d, stat_count, stat_radii,
+              stat_use_abs);
     MI_LAUNCH_CHECK();
     return 0;
 }

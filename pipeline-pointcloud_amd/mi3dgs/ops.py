@@ -122,6 +122,26 @@ def project_bwd(means, quats, scales, opacities, viewmats, Ks, width, height, ra
     return o
 
 
+def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, height, radii, splats, v_splats, *,
+                     n, sh_degree, eps2d=0.3, flags=0, beta1=0.9, beta2=0.999, eps=1e-15, scale_reg_weight=0.0,
+                     scale_reg_max_ratio=10.0, stats=None, stat_use_abs=False):
+    """Single-camera backward with the Adam step fused in: `params` (list of the 6 group
+    tensors means, quats, scales, opacities, sh0, shN) are updated in place, no gradients are
+    materialised.  `n` = live Gaussians (the tensors may be larger: capacity)."""
+    dev = params[0].device
+    for t in list(params) + list(exp_avg) + list(exp_avg_sq):
+        _chk(t, "parameter / moment buffer")
+    sg = sc = sr = None
+    if stats is not None:
+        sg, sc, sr = stats.get("grad2d"), stats.get("count"), stats.get("radii")
+    lr = (C.c_float * 6)(*[float(x) for x in lrs])
+    _lib.call("mi3dgs_project_bwd_adam", int(n), _p(params[0]), _p(params[1]), _p(params[2]), _p(params[3]),
+              _p(params[4]), _p(params[5]), int(sh_degree), _p(viewmat), _p(K), int(width), int(height), float(eps2d),
+              int(flags), _p(radii), _p(splats), _p(v_splats), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), lr, int(step),
+              float(beta1), float(beta2), float(eps), float(scale_reg_weight), float(scale_reg_max_ratio), _p(sg), _p(sc),
+              _p(sr), int(bool(stat_use_abs)), _stream(dev))
+
+
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
               want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False):
     """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops

@@ -122,6 +122,9 @@ class DataParallelTrainer(Trainer):
         m = self.model
         return [m.grads[g][: m.n] for g in GROUPS]
 
+    def _can_fuse_adam(self) -> bool:
+        return not self.ctx.active          # the gradients have to exist to be all-reduced
+
     def _all_reduce_grads(self):
         allreduce_mean_(self._live_grads(), self.ctx)
 

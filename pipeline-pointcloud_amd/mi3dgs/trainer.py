@@ -69,6 +69,9 @@ class TrainConfig:
     max_isect: Optional[int] = None
     # exact ellipse-tile culling at binning time (identical renders/gradients, fewer intersections)
     tight_tiles: bool = True
+    # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
+    # gradients for its all-reduce and switches this off)
+    fuse_adam: bool = True
     seed: int = 0
 
 
@@ -193,19 +196,28 @@ class Trainer:
         v_splats.zero_()
         ops.rasterize_bwd(splats, binning, self.W, self.H, alphas, last_ids, self.v_render, self.v_alphas, 16, bg,
                           c.absgrad, v_splats)
-        grads = {"v_" + g: m.grad(g) for g in GROUPS}
         track = c.densify and self.step_count < c.refine_stop_iter
         stats = {k: v[:n] for k, v in self.stats.items()} if track else None
-        ops.project_bwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
-                        radii, splats, v_splats, sh0=m.p("sh0"), shN=m.p("shN"), color_mode=ops.COLOR_SH,
-                        sh_degree=sd, flags=self._flags(), out=grads, stats=stats, stat_use_abs=c.absgrad)
-        if c.use_scale_regularization and self.step_count % c.scale_reg_every == 0:
-            ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
-        self._all_reduce_grads()
-        ops.adam_step([m.banks[m.cur][g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS],
-                      [m.banks[m.cur][g]["m"] for g in GROUPS], [m.banks[m.cur][g]["v"] for g in GROUPS],
-                      self.lrs(), self.step_count + 1, beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
-                      numel=[n * w for w in WIDTHS])
+        sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
+        bank = m.banks[m.cur]
+        if c.fuse_adam and self._can_fuse_adam():
+            ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
+                                 [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, viewmat, K, self.W,
+                                 self.H, radii, splats, v_splats, n=n, sh_degree=sd, flags=self._flags(),
+                                 beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                                 scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
+                                 scale_reg_max_ratio=c.max_gauss_ratio, stats=stats, stat_use_abs=c.absgrad)
+        else:
+            grads = {"v_" + g: m.grad(g) for g in GROUPS}
+            ops.project_bwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
+                            radii, splats, v_splats, sh0=m.p("sh0"), shN=m.p("shN"), color_mode=ops.COLOR_SH,
+                            sh_degree=sd, flags=self._flags(), out=grads, stats=stats, stat_use_abs=c.absgrad)
+            if sreg:
+                ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
+            self._all_reduce_grads()
+            ops.adam_step([bank[g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
+                          [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, beta1=c.adam_beta1,
+                          beta2=c.adam_beta2, eps=c.adam_eps, numel=[n * w for w in WIDTHS])
         if c.densify:
             self._strategy_post_step()
         self.last = dict(binning=binning, sums=sums)
@@ -217,6 +229,9 @@ class Trainer:
     def _all_reduce_grads(self):
         """Hook for the replicated-Gaussian data-parallel mode (parallel.py); no-op on one GPU."""
         return
+
+    def _can_fuse_adam(self) -> bool:
+        return True
 
     # -- DefaultStrategy.step_post_backward --------------------------------------------
     def _strategy_post_step(self):

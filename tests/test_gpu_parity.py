@@ -394,3 +394,37 @@ def test_tight_binning_is_conservative_and_renders_bit_identical(dev, seed, big)
     g1 = ops.rasterize_bwd(splats, tight, sc.width, sc.height, a1, l1, vr, va, 16, bg)
     assert rel_err(g1, g0) < 1e-5
     print(f"intersections: box {n_box}, tight {n_tight} ({100.0 * n_tight / n_box:.0f} %), exact {need.numel()}")
+
+
+# --------------------------------------------------------- Adam fused into the backward
+@pytest.mark.parametrize("n,scale_reg", [(700, False), (333, True), (64, True)])
+def test_fused_adam_backward_equals_separate_kernels(dev, n, scale_reg):
+    """Same step through project_bwd + (scale_reg) + adam_step and through project_bwd_adam."""
+    from mi3dgs import trainer
+    sc = small_scene(n=n, seed=51, big=True, width=80, height=56, n_views=3)
+    sc.params["scales"][: n // 3, 0] += 2.5           # ratios above max_gauss_ratio: the regulariser is active
+    g = sc.to(dev)
+    imgs = torch.rand(3, 56, 80, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    out = {}
+    for fuse in (False, True):
+        cfg = trainer.TrainConfig(max_steps=50, densify=True, refine_start_iter=10 ** 9, sh_degree_interval=1,
+                                  use_scale_regularization=scale_reg, scale_reg_every=1, fuse_adam=fuse, capacity=n + 40)
+        tr = trainer.Trainer({k: v.clone() for k, v in g.params.items()}, g.viewmats, g.Ks, imgs, 80, 56, cfg)
+        for s in range(5):
+            tr.step(s % 3)
+        out[fuse] = ({k: tr.model.p(k).clone() for k in trainer.GROUPS},
+                     {k: tr.model.state(k, "m").clone() for k in trainer.GROUPS},
+                     {k: tr.model.state(k, "v").clone() for k in trainer.GROUPS},
+                     {k: v[:n].clone() for k, v in tr.stats.items()},
+                     {k: tr.model.banks[0][k]["p"][n:].clone() for k in trainer.GROUPS})
+    for part in range(4):
+        for k in out[True][part]:
+            a, b = out[True][part][k], out[False][part][k]
+            # two separate runs: rasterize_bwd's float atomics sum in a different order each time,
+            # and 5 Adam steps (eps 1e-15) amplify that; a fusion bug would show at the 1e-1 level
+            assert rel_err(a, b) < 1e-3, (part, k, rel_err(a, b))
+    # nothing beyond the live Gaussians is touched (capacity tail)
+    for k in trainer.GROUPS:
+        assert float(out[True][4][k].abs().max()) == 0.0
+    # and the step really moved the parameters
+    assert rel_err(out[True][0]["means"], g.params["means"]) > 1e-6
