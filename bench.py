@@ -49,18 +49,26 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
     return ap.parse_args()
 
 
-def setup_dist(n_gpus):
+def setup_dist(n_gpus, rehearse=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL
     elif n_gpus > 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     return rank, world, local
@@ -230,7 +238,7 @@ def main():
     args = parse()
     if args.cpu_leg:
         return cpu_leg_main(args.cpu_leg)
-    rank, world, local = setup_dist(args.gpus)
+    rank, world, local = setup_dist(args.gpus, args.rehearse)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -239,9 +247,10 @@ def main():
     sc, tr, V = build_workload(args, rank, dev)
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local])
+            dist.barrier() if args.rehearse else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     log("warmup")
@@ -256,7 +265,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     its = world * args.steps / dt
@@ -346,7 +355,7 @@ def main():
                 roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, **common)
         cpu = None
         log("stage profile done; cpu baseline")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU leg runs at N = 1 only
             cpu = cpu_baseline(sc, tr, 0)
             log(f"cpu baseline: {cpu.get('value')}")
         result = {
@@ -363,7 +372,7 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier(device_ids=[local])
+        dist.barrier() if args.rehearse else dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

@@ -181,7 +181,9 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
             now = time.time()
             rate = (step - s_last + 1) / max(now - t_last, 1e-9)
             t_last, s_last = now, step + 1
-            say(f"step {step + 1}/{cfg.max_steps} loss={loss:.5f} gaussians={tr.model.n} | {rate:.1f} it/s")
+            rt = tr.refine_totals
+            extra = f" (+{rt.get('n_dup', 0)} dup +{rt.get('n_split', 0)} split -{rt.get('n_prune', 0)} pruned)" if rt else ""
+            say(f"step {step + 1}/{cfg.max_steps} loss={loss:.5f} gaussians={tr.model.n}{extra} | {rate:.1f} it/s")
         if (step + 1) in save_steps and on_save is not None:
             on_save(tr, ds, step)
     torch.cuda.synchronize()

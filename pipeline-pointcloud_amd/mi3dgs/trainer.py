@@ -139,6 +139,8 @@ class Trainer:
         self.total_buf = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
         self.last: Dict = {}
+        self.last_refine: Dict = {}
+        self.refine_totals: Dict = {}
 
     # -- helpers -------------------------------------------------------------------
     def _n(self) -> int:
@@ -274,6 +276,8 @@ class Trainer:
         m.n = new_n
         for v in self.stats.values():
             v.zero_()
+        self.last_refine = info
+        self.refine_totals = {k: self.refine_totals.get(k, 0) + info[k] for k in ("n_dup", "n_split", "n_prune")}
         return info
 
     def reset_opacity(self):

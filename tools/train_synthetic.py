@@ -1,0 +1,80 @@
+"""End-to-end run on a synthetic COLMAP dataset (there are no real datasets in this image):
+ground-truth Gaussians -> rendered views + SfM-like sparse points on disk -> the `ns-train`
+or `simple_trainer.py` shim -> held-out PSNR, Gaussian count, it/s.
+
+  python tools/train_synthetic.py --gt 200000 --views 60 --width 960 --height 540 --steps 7000
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pipeline-pointcloud_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gt", type=int, default=200_000)
+    ap.add_argument("--points", type=int, default=20_000)
+    ap.add_argument("--views", type=int, default=60)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--steps", type=int, default=7000)
+    ap.add_argument("--mode", default="simple_trainer", choices=["simple_trainer", "ns-train"])
+    ap.add_argument("--strategy", default="default", choices=["default", "mcmc"])
+    ap.add_argument("--keep", default=None, help="directory to keep the dataset and outputs in")
+    a = ap.parse_args()
+    from PIL import Image
+    from mi3dgs import cli, io_colmap, scenes, trainer
+    dev = torch.device("cuda:0")
+    root = a.keep or tempfile.mkdtemp(prefix="mi3dgs_synth_")
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    t0 = time.time()
+    sc = scenes.make_garden_like(n=a.gt, seed=7, width=a.width, height=a.height, n_views=a.views,
+                                 fx=1450.0 * a.width / 1920.0)
+    sc.params["opacities"] += 1.5                          # a mostly opaque scene, like a trained one
+    sc.params["scales"] += np.log(2.5 * (2_000_000 / a.gt) ** (1 / 3))   # keep the surface covered at lower counts
+    g = sc.to(dev)
+    tr = trainer.Trainer(g.params, g.viewmats, g.Ks, torch.zeros(1, 1, 1, 3, device=dev), a.width, a.height,
+                         trainer.TrainConfig(densify=False))
+    cams = [io_colmap.Camera(1, "PINHOLE", a.width, a.height,
+                             np.array([float(sc.Ks[0, 0, 0]), float(sc.Ks[0, 1, 1]), a.width / 2, a.height / 2]))]
+    ims = []
+    bg = torch.full((1, 3), 0.2, device=dev)
+    for i in range(a.views):
+        img = tr.render(g.viewmats[i], g.Ks[i], background=bg)[0][0].clamp(0, 1)
+        Image.fromarray((img * 255).round().byte().cpu().numpy()).save(os.path.join(root, "images", f"f_{i:04d}.png"))
+        V = sc.viewmats[i].double().numpy()
+        ims.append(io_colmap.Image(i + 1, io_colmap.rotmat_to_qvec(V[:3, :3]), V[:3, 3].copy(), 1, f"f_{i:04d}.png"))
+    sel = torch.randperm(a.gt, generator=torch.Generator().manual_seed(1))[: a.points]
+    xyz = (sc.params["means"][sel] + 0.01 * torch.randn(a.points, 3)).double().numpy()
+    rgb = ((0.5 + 0.2820948 * sc.params["sh0"][sel, 0]).clamp(0, 1) * 255).byte().numpy()
+    sparse = os.path.join(root, "sparse", "0") if a.mode == "simple_trainer" else os.path.join(root, "colmap", "sparse", "0")
+    io_colmap.write_model(sparse, cams, ims, xyz, rgb)
+    del tr
+    torch.cuda.empty_cache()
+    print(f"[synthetic] dataset in {root}: {a.views} views {a.width}x{a.height}, {a.points} points, "
+          f"made in {time.time() - t0:.1f}s", flush=True)
+    if a.mode == "simple_trainer":
+        res = os.path.join(root, "exports")
+        cli.main_simple_trainer([a.strategy, "--max_steps", str(a.steps), "--result-dir", res, "--data_factor", "1",
+                                 "--steps_scaler", "1.0", "--disable_viewer", "--packed", "--batch-size", "1",
+                                 "--data-dir", root])
+        st = json.load(open(os.path.join(res, "stats", f"val_step{a.steps - 1:04d}.json")))
+    else:
+        os.chdir(root)
+        model = "splatfacto-mcmc" if a.strategy == "mcmc" else "splatfacto"
+        cli.main_ns_train([model, "--timestamp", "train-stage-1", "--pipeline.model.use_scale_regularization=True",
+                           "--max-num-iterations", str(a.steps), "colmap", "--data", root, "--downscale-factor", "1"])
+        st = json.loads("".join(l for l in open("outputs/unnamed/splatfacto/train-stage-1/config.yml") if not l.startswith("#")))["stats"]
+    print("[synthetic] result:", json.dumps(st), flush=True)
+
+
+if __name__ == "__main__":
+    main()
