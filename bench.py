@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="garden", choices=["cube", "lego", "garden", "6m"])
-    ap.add_argument("--n", type=int, default=None, help="override the Gaussian count")
+    ap.add_argument("--gaussians", dest="n", type=int, default=None, help="override the Gaussian count")
     ap.add_argument("--views", type=int, default=8, help="target views kept resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")

@@ -6,7 +6,7 @@ import torch
 import bench
 from mi3dgs import _lib
 
-class A: scene="garden"; n=None; views=2; sync_isect=False
+class A: scene="garden"; n=None; views=2; sync_isect=False; rehearse=False
 sc, tr, V = bench.build_workload(A, 0, torch.device("cuda:0"))
 h = _lib.lib()
 buf = (ctypes.c_ulonglong * 8)()
