@@ -191,6 +191,21 @@ int mi3dgs_densify_scatter(int N, const float* const* params_in, const float* co
 int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_logit, float* exp_avg,
                          float* exp_avg_sq, void* stream);
 
+/* ---- MCMC strategy ----------------------------------------------------------------------
+ * Replaces gsplat MCMCStrategy's compute_relocation kernel, inject_noise_to_position and the
+ * opacity / scale regularisers of `simple_trainer.py mcmc` / `splatfacto-mcmc` (reference
+ * main.py:1285-1291, 1324-1327).  relocation: ACTIVATED opacities[n] / scales[n,3], ratios[n]
+ * copies each, binoms[51*51] = C(n,k) table.  inject_noise: means += Sigma (randn * gate(o) *
+ * scaler), gate = sigmoid(-100 (o - 0.005)).  regularise: accumulates d/d(logit, log-scale) of
+ * opacity_reg*mean(sigmoid(o)) + scale_reg*mean(exp(s)). */
+int mi3dgs_mcmc_relocation(int n, const float* opacities, const float* scales, const int32_t* ratios,
+                           const float* binoms, float* new_opacities, float* new_scales, void* stream);
+int mi3dgs_mcmc_inject_noise(int N, float* means, const float* quats, const float* scales_log,
+                             const float* opacities_logit, float scaler, uint32_t seed, void* stream);
+int mi3dgs_mcmc_regularise(int N, const float* opacities_logit, const float* scales_log,
+                           float opacity_reg, float scale_reg, float* v_opacities, float* v_scales,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,3 +431,18 @@ def contributing_pairs(means2d, conics, opacities, radii, width: int, height: in
             tiles = torch.unique(tile_of_px[hit])
             out.append((c * tw * th + tiles) * N + g)
     return torch.sort(torch.cat(out)).values if out else torch.zeros(0, dtype=torch.int64)
+
+
+# ------------------------------------------------------------------------ MCMC relocation
+def mcmc_relocation(opacities: torch.Tensor, scales: torch.Tensor, ratios: torch.Tensor):
+    """gsplat `compute_relocation` ("3DGS as MCMC", eq. 9): a Gaussian replaced by `ratio` co-located
+    copies: o' = 1 - (1-o)^(1/ratio); s' = s o / sum_{i=1..ratio} sum_{k<i} C(i-1,k) (-1)^k o'^(k+1) / sqrt(k+1)."""
+    no = 1.0 - (1.0 - opacities) ** (1.0 / ratios.to(opacities.dtype))
+    denom = torch.zeros_like(opacities)
+    for j in range(opacities.shape[0]):
+        d = 0.0
+        for i in range(1, int(ratios[j]) + 1):
+            for k in range(i):
+                d += math.comb(i - 1, k) * (-1) ** k * float(no[j]) ** (k + 1) / math.sqrt(k + 1)
+        denom[j] = d
+    return no, scales * (opacities / denom)[:, None]

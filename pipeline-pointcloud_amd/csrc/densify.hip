@@ -189,3 +189,120 @@ extern "C" int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_log
     MI_LAUNCH_CHECK();
     return 0;
 }
+
+// ======================================================================================
+// MCMC strategy ("3D Gaussian Splatting as Markov Chain Monte Carlo", Kheradmand et al. 2024;
+// gsplat MCMCStrategy + relocation.cu), selected by the reference with MODEL=splatfacto-mcmc
+// (main.py:1285-1291) or `simple_trainer.py mcmc` (main.py:1324-1327).  Two kernels; the
+// multinomial sampling and the row copies around them are host-side tensor plumbing.
+// ======================================================================================
+namespace {
+
+constexpr int RELOC_N_MAX = 51;
+
+// A Gaussian that is about to be split into `ratio` co-located copies keeps the rendered
+// result (to first order) if every copy gets
+//   o' = 1 - (1 - o)^(1/ratio),   s' = s * o / sum_{i=1..ratio} sum_{k=0..i-1} C(i-1,k) (-1)^k o'^(k+1) / sqrt(k+1)
+__global__ __launch_bounds__(256) void mcmc_relocation_kernel(int n, const float* __restrict__ opac_in,
+                                                              const float* __restrict__ scale_in,
+                                                              const int32_t* __restrict__ ratios,
+                                                              const float* __restrict__ binoms,
+                                                              float* __restrict__ opac_out, float* __restrict__ scale_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int N = min(max(ratios[i], 1), RELOC_N_MAX);
+    float o = opac_in[i];
+    float no = 1.f - powf(1.f - o, 1.f / (float)N);
+    float denom = 0.f;
+    for (int a = 1; a <= N; a++) {
+        float pw = no;                 // no^(k+1)
+        for (int k = 0; k < a; k++) {
+            float term = binoms[(a - 1) * RELOC_N_MAX + k] * ((k & 1) ? -1.f : 1.f) * pw * rsqrtf((float)(k + 1));
+            denom += term;
+            pw *= no;
+        }
+    }
+    float coeff = o / denom;
+    opac_out[i] = no;
+    scale_out[3 * i] = coeff * scale_in[3 * i];
+    scale_out[3 * i + 1] = coeff * scale_in[3 * i + 1];
+    scale_out[3 * i + 2] = coeff * scale_in[3 * i + 2];
+}
+
+// means += Sigma * (randn(3) * gate(opacity) * scaler),  gate(o) = sigmoid(-k (o - (1 - x0)))
+// with k = 100, x0 = 0.995: only nearly transparent Gaussians are perturbed.
+__global__ __launch_bounds__(256) void mcmc_noise_kernel(int N, float* __restrict__ means, const float* __restrict__ quats,
+                                                         const float* __restrict__ scales_log,
+                                                         const float* __restrict__ opac_logit, float scaler,
+                                                         uint32_t seed) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float o = sigmoidf_(opac_logit[n]);
+    float gate = 1.f / (1.f + __expf(-100.f * ((1.f - o) - 0.995f)));
+    float amp = gate * scaler;
+    if (amp == 0.f) return;
+    const float* q = quats + 4 * (size_t)n;
+    float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    float inv = rsqrtf(fmaxf(n2, 1e-24f));
+    float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
+                  2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                  2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
+    float s2[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { float e = __expf(scales_log[3 * n + i]); s2[i] = e * e; }
+    float r0, r1, r2, r3;
+    randn2(seed, (uint32_t)n * 2u, r0, r1);
+    randn2(seed, (uint32_t)n * 2u + 1u, r2, r3);
+    float e[3] = {r0 * amp, r1 * amp, r2 * amp};
+    // Sigma e = R S^2 R^T e
+    float t[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[j] = (R[j] * e[0] + R[3 + j] * e[1] + R[6 + j] * e[2]) * s2[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) means[3 * n + i] += R[3 * i] * t[0] + R[3 * i + 1] * t[1] + R[3 * i + 2] * t[2];
+}
+
+// gradients of opacity_reg * mean(sigmoid(o)) + scale_reg * mean(exp(s)), accumulated
+__global__ __launch_bounds__(256) void mcmc_reg_kernel(int N, const float* __restrict__ opac_logit,
+                                                       const float* __restrict__ scales_log, float opacity_reg,
+                                                       float scale_reg, float* __restrict__ v_opac,
+                                                       float* __restrict__ v_scales) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float o = sigmoidf_(opac_logit[n]);
+    v_opac[n] += opacity_reg * o * (1.f - o) / (float)N;
+#pragma unroll
+    for (int i = 0; i < 3; i++) v_scales[3 * n + i] += scale_reg * __expf(scales_log[3 * n + i]) / (3.f * (float)N);
+}
+
+}  // namespace
+
+// opacities / scales are ACTIVATED values (sigmoid / exp); ratios[i] = number of copies the
+// Gaussian is split into; binoms = [51][51] table of binomial coefficients C(n, k).
+extern "C" int mi3dgs_mcmc_relocation(int n, const float* opacities, const float* scales, const int32_t* ratios,
+                                      const float* binoms, float* new_opacities, float* new_scales, void* stream) {
+    if (n <= 0) return 0;
+    MI_LAUNCH("mcmc_relocation", mcmc_relocation_kernel, dim3(mi_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+              opacities, scales, ratios, binoms, new_opacities, new_scales);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_mcmc_inject_noise(int N, float* means, const float* quats, const float* scales_log,
+                                        const float* opacities_logit, float scaler, uint32_t seed, void* stream) {
+    if (N <= 0) return 0;
+    MI_LAUNCH("mcmc_noise", mcmc_noise_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means, quats,
+              scales_log, opacities_logit, scaler, seed);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_mcmc_regularise(int N, const float* opacities_logit, const float* scales_log, float opacity_reg,
+                                      float scale_reg, float* v_opacities, float* v_scales, void* stream) {
+    if (N <= 0) return 0;
+    MI_LAUNCH("mcmc_reg", mcmc_reg_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, opacities_logit,
+              scales_log, opacity_reg, scale_reg, v_opacities, v_scales);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

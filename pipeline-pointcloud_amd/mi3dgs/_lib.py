@@ -54,6 +54,9 @@ _SIGNATURES = {
     "mi3dgs_densify_scatter": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
                                     C.POINTER(_f), _f, _f, _ll, _u32, _f]),
     "mi3dgs_reset_opacity": (_i, [_i, _f, _fl, _f, _f, _f]),
+    "mi3dgs_mcmc_relocation": (_i, [_i, _f, _f, _f, _f, _f, _f, _f]),
+    "mi3dgs_mcmc_inject_noise": (_i, [_i, _f, _f, _f, _f, _fl, _u32, _f]),
+    "mi3dgs_mcmc_regularise": (_i, [_i, _f, _f, _fl, _fl, _f, _f, _f]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

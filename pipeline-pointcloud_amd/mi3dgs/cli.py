@@ -140,7 +140,7 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int = 100, save_steps=(),
-                 on_save=None) -> Tuple[object, object, Dict]:
+                 on_save=None, strategy: str = "default", cap_max: int = 1_000_000) -> Tuple[object, object, Dict]:
     """Loads the dataset, trains, evaluates.  Returns (trainer, dataset, stats)."""
     from . import dataset as ds_mod
     from . import parallel
@@ -159,9 +159,16 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb)
     imgs = ds.load_images(ds.train_idx, dev)
     vm, ks = ds.viewmats[ds.train_idx].to(dev), ds.Ks[ds.train_idx].to(dev)
-    cls = parallel.DataParallelTrainer if (ctx is not None and ctx.active) else Trainer
-    kw = {"ctx": ctx} if cls is parallel.DataParallelTrainer else {}
-    tr = cls(params, vm, ks, imgs, ds.width, ds.height, cfg, **kw)
+    if strategy == "mcmc":
+        from .strategy_mcmc import MCMCConfig, MCMCTrainer
+        if ctx is not None and ctx.active:
+            raise SystemExit("mi3dgs: the mcmc strategy is single-GPU only for now")
+        tr = MCMCTrainer(params, vm, ks, imgs, ds.width, ds.height, cfg,
+                         MCMCConfig(cap_max=cap_max, refine_stop_iter=max(1, int(cfg.max_steps * 25 / 30))))
+    else:
+        cls = parallel.DataParallelTrainer if (ctx is not None and ctx.active) else Trainer
+        kw = {"ctx": ctx} if cls is parallel.DataParallelTrainer else {}
+        tr = cls(params, vm, ks, imgs, ds.width, ds.height, cfg, **kw)
     say(f"loaded in {time.time() - t0:.1f}s; training {cfg.max_steps} steps from {tr.model.n} Gaussians "
         f"(capacity {tr.model.capacity})")
     V = len(ds.train_idx)
@@ -216,11 +223,11 @@ def main_ns_train(argv: Optional[List[str]] = None) -> int:
         raise SystemExit(f"ns-train (mi3dgs): model {a['model']!r} is not implemented; supported: {SPLATFACTO_MODELS}")
     if a["dataparser"] != "colmap" or not a["data"]:
         raise SystemExit("ns-train (mi3dgs): only `colmap --data DIR` datasets are implemented")
-    if a["model"] == "splatfacto-mcmc":
-        say("note: splatfacto-mcmc runs with the default densification strategy (MCMC relocation is not implemented yet)")
-    cap = int(float(a["opts"].get("--max-gaussians", 8_000_000)))
+    mcmc = a["model"] == "splatfacto-mcmc"
+    cap = int(float(a["opts"].get("--max-gaussians", 1_000_000 if mcmc else 8_000_000)))   # splatfacto-mcmc max_gs_num 1e6
     tr, ds, stats = run_training(a["data"], a["downscale"], lambda ds: splatfacto_config(
-        a["model"], a["max_steps"], a["scale_reg"], max(1, len(ds.train_idx)), cap))
+        a["model"], a["max_steps"], a["scale_reg"], max(1, len(ds.train_idx)), cap),
+        strategy="mcmc" if mcmc else "default", cap_max=cap)
     cfg = tr.cfg
     out_dir = os.path.join("outputs", "unnamed", "splatfacto", a["timestamp"])       # the path main.py:2158 copies from
     os.makedirs(os.path.join(out_dir, "nerfstudio_models"), exist_ok=True)
@@ -285,7 +292,8 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
 
     save_steps = {max(1, int(s * a["steps_scaler"])) for s in (7000, 30000)}
     tr, ds, stats = run_training(a["data_dir"], a["data_factor"], cfg, ctx=ctx if world > 1 else None,
-                                 save_steps=save_steps, on_save=save)
+                                 save_steps=save_steps, on_save=save, strategy=a["strategy"],
+                                 cap_max=min(a["max_gaussians"], 1_000_000) if a["strategy"] == "mcmc" else a["max_gaussians"])
     save(tr, ds, cfg.max_steps - 1)            # every rank holds the full (replicated) model
     if rank == 0:
         os.makedirs(os.path.join(a["result_dir"], "stats"), exist_ok=True)
@@ -301,9 +309,9 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
 def main_simple_trainer(argv: Optional[List[str]] = None) -> int:
     """Like gsplat's own launcher: one process per visible GPU (it ignores torchrun's env)."""
     a = parse_simple_trainer(sys.argv[1:] if argv is None else argv)
-    if a["strategy"] == "mcmc":
-        say("note: `mcmc` runs with the default densification strategy (MCMC relocation is not implemented yet)")
     world = torch.cuda.device_count()
+    if a["strategy"] == "mcmc":
+        world = 1                      # the mcmc strategy is single-GPU for now
     if world <= 1:
         _simple_trainer_rank(0, 1, 0, a)
         return 0

@@ -1,0 +1,140 @@
+"""MCMC densification strategy (gsplat MCMCStrategy; "3D Gaussian Splatting as Markov Chain
+Monte Carlo"), what the reference selects with MODEL=splatfacto-mcmc
+(source/container/src/main.py:1285-1291) or `simple_trainer.py mcmc` (main.py:1324-1327).
+
+Per step, after Adam: positional noise on nearly transparent Gaussians.  Every `refine_every`
+steps between refine_start_iter and refine_stop_iter: dead Gaussians (opacity <= min_opacity)
+are teleported onto live ones sampled in proportion to opacity, then the set grows by 5 % up to
+`cap_max`; sources and copies get the relocation opacity / scale, sources lose their Adam
+state.  Loss adds opacity_reg * mean(opacity) + scale_reg * mean(scale).
+Defaults [UPSTREAM-UNVERIFIED, SURVEY.md Appendix A].  The two arithmetic kernels are HIP
+(csrc/densify.hip); multinomial sampling and row copies are tensor plumbing, every 100 steps.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .trainer import GROUPS, TrainConfig, Trainer
+
+N_MAX = 51
+
+
+@dataclasses.dataclass
+class MCMCConfig:
+    cap_max: int = 1_000_000
+    noise_lr: float = 5e5
+    min_opacity: float = 0.005
+    opacity_reg: float = 0.01
+    scale_reg: float = 0.01
+    refine_start_iter: int = 500
+    refine_stop_iter: int = 25_000
+    refine_every: int = 100
+
+
+def binom_table(device) -> torch.Tensor:
+    t = torch.zeros(N_MAX, N_MAX, dtype=torch.float32)
+    for n in range(N_MAX):
+        for k in range(n + 1):
+            t[n, k] = math.comb(n, k)
+    return t.to(device)
+
+
+def compute_relocation(opacities: torch.Tensor, scales: torch.Tensor, ratios: torch.Tensor, binoms: torch.Tensor):
+    """ACTIVATED opacities[n], scales[n,3], ratios[n] int32 -> (new opacities, new scales)."""
+    n = opacities.shape[0]
+    no, ns = torch.empty_like(opacities), torch.empty_like(scales)
+    ops._lib.call("mi3dgs_mcmc_relocation", n, ops._p(opacities.contiguous()), ops._p(scales.contiguous()),
+                  ops._p(ratios.to(torch.int32).contiguous()), ops._p(binoms), ops._p(no), ops._p(ns),
+                  ops._stream(opacities.device))
+    return no, ns
+
+
+class MCMCTrainer(Trainer):
+    def __init__(self, params, viewmats, Ks, images, width, height, cfg: Optional[TrainConfig] = None,
+                 mcmc: Optional[MCMCConfig] = None):
+        cfg = dataclasses.replace(cfg or TrainConfig(), densify=False, fuse_adam=False)
+        self.mcmc = mcmc or MCMCConfig()
+        if cfg.capacity is None or cfg.capacity < self.mcmc.cap_max:
+            cfg = dataclasses.replace(cfg, capacity=max(self.mcmc.cap_max, params["means"].shape[0]))
+        super().__init__(params, viewmats, Ks, images, width, height, cfg)
+        self.binoms = binom_table(self.device)
+        self.tgen = torch.Generator(device=self.device).manual_seed(cfg.seed + 77)
+        self.mcmc_totals = dict(relocated=0, added=0)
+
+    # gradients of the two regularisers, between the backward and Adam
+    def _all_reduce_grads(self):
+        m, c = self.model, self.mcmc
+        ops._lib.call("mi3dgs_mcmc_regularise", m.n, ops._p(m.p("opacities")), ops._p(m.p("scales")), float(c.opacity_reg),
+                      float(c.scale_reg), ops._p(m.grad("opacities")), ops._p(m.grad("scales")), ops._stream(self.device))
+
+    @torch.no_grad()
+    def step(self, view_index: int, want_loss: bool = False):
+        step = self.step_count
+        out = super().step(view_index, want_loss)
+        c, m = self.mcmc, self.model
+        if c.refine_start_iter < step < c.refine_stop_iter and step % c.refine_every == 0:
+            self.mcmc_totals["relocated"] += self.relocate()
+            self.mcmc_totals["added"] += self.add_new()
+        seed = (self.cfg.seed * 2654435761 + step * 40503 + 17) & 0xFFFFFFFF
+        lr_means = self.lrs()[0]
+        ops._lib.call("mi3dgs_mcmc_inject_noise", m.n, ops._p(m.p("means")), ops._p(m.p("quats")), ops._p(m.p("scales")),
+                      ops._p(m.p("opacities")), float(lr_means * c.noise_lr), seed, ops._stream(self.device))
+        self.refine_totals = dict(n_dup=self.mcmc_totals["added"], n_split=self.mcmc_totals["relocated"], n_prune=0)
+        return out
+
+    # -- helpers -------------------------------------------------------------------
+    def _rows(self, g: str, k: str = "p") -> torch.Tensor:
+        return self.model.banks[self.model.cur][g][k]
+
+    def _apply_relocation(self, sampled: torch.Tensor):
+        """New opacity / scale for the sampled sources (ratio = times sampled + 1); zero their Adam state."""
+        m, c = self.model, self.mcmc
+        op = torch.sigmoid(self._rows("opacities")[sampled, 0])
+        sc = torch.exp(self._rows("scales")[sampled])
+        counts = torch.bincount(sampled, minlength=m.n)[sampled] + 1
+        no, ns = compute_relocation(op, sc, counts.clamp(max=N_MAX), self.binoms)
+        no = no.clamp(min=c.min_opacity, max=1.0 - 1e-7)
+        self._rows("opacities")[sampled, 0] = torch.log(no / (1.0 - no))
+        self._rows("scales")[sampled] = torch.log(ns)
+        for g in GROUPS:
+            self._rows(g, "m")[sampled] = 0.0
+            self._rows(g, "v")[sampled] = 0.0
+
+    def relocate(self) -> int:
+        m, c = self.model, self.mcmc
+        n = m.n
+        op = torch.sigmoid(self._rows("opacities")[:n, 0])
+        dead = op <= c.min_opacity
+        n_dead = int(dead.sum())
+        if n_dead == 0 or n_dead == n:
+            return 0
+        alive_idx = torch.nonzero(~dead).flatten()
+        pick = torch.multinomial(op[alive_idx], n_dead, replacement=True, generator=self.tgen)
+        sampled = alive_idx[pick]
+        self._apply_relocation(sampled)
+        dead_idx = torch.nonzero(dead).flatten()
+        for g in GROUPS:
+            self._rows(g)[dead_idx] = self._rows(g)[sampled]
+        return n_dead
+
+    def add_new(self) -> int:
+        m, c = self.model, self.mcmc
+        n = m.n
+        target = min(c.cap_max, m.capacity, int(1.05 * n))
+        n_new = max(0, target - n)
+        if n_new == 0:
+            return 0
+        op = torch.sigmoid(self._rows("opacities")[:n, 0])
+        sampled = torch.multinomial(op, n_new, replacement=True, generator=self.tgen)
+        self._apply_relocation(sampled)
+        for g in GROUPS:
+            self._rows(g)[n:n + n_new] = self._rows(g)[sampled]
+            self._rows(g, "m")[n:n + n_new] = 0.0
+            self._rows(g, "v")[n:n + n_new] = 0.0
+        m.n = n + n_new
+        return n_new

@@ -428,3 +428,67 @@ def test_fused_adam_backward_equals_separate_kernels(dev, n, scale_reg):
         assert float(out[True][4][k].abs().max()) == 0.0
     # and the step really moved the parameters
     assert rel_err(out[True][0]["means"], g.params["means"]) > 1e-6
+
+
+# --------------------------------------------------------------------------- MCMC strategy
+def test_mcmc_relocation_matches_oracle(dev):
+    from mi3dgs import strategy_mcmc
+    g = torch.Generator().manual_seed(7)
+    n = 300
+    op = torch.rand(n, generator=g) * 0.98 + 0.01
+    sc = torch.rand(n, 3, generator=g) * 0.1 + 0.001
+    ratios = torch.randint(1, 12, (n,), generator=g)
+    ratios[:5] = torch.tensor([1, 2, 51, 30, 1])
+    no_ref, ns_ref = O.mcmc_relocation(op.double(), sc.double(), ratios)
+    no, ns = strategy_mcmc.compute_relocation(op.to(dev), sc.to(dev), ratios.to(dev), strategy_mcmc.binom_table(dev))
+    assert rel_err(no.cpu(), no_ref) < 1e-5 and rel_err(ns.cpu(), ns_ref) < 2e-4
+    one = ratios == 1
+    assert torch.allclose(no.cpu()[one], op[one], atol=1e-6) and torch.allclose(ns.cpu()[one], sc[one], rtol=1e-5)
+
+
+def test_mcmc_noise_statistics(dev):
+    from mi3dgs import ops
+    n = 20000
+    means = torch.zeros(n, 3, device=dev)
+    quats = torch.tensor([[0.9, 0.1, -0.3, 0.2]], device=dev).repeat(n, 1)
+    ls = torch.log(torch.tensor([[0.5, 0.1, 0.02]], device=dev)).repeat(n, 1).contiguous()
+    opa = torch.full((n,), -9.0, device=dev)          # sigmoid ~ 1e-4: gate ~ 1
+    opa[n // 2:] = 3.0                                  # opaque: gate ~ 0
+    ops._lib.call("mi3dgs_mcmc_inject_noise", n, ops._p(means), ops._p(quats), ops._p(ls), ops._p(opa), 2.0, 1234,
+                  ops._stream(dev))
+    moved, still = means[: n // 2].double().cpu(), means[n // 2:]
+    assert float(still.abs().max()) < 1e-6
+    R = O.quat_to_rotmat(quats[:1].double().cpu())[0]
+    Sig = R @ torch.diag(torch.tensor([0.5, 0.1, 0.02], dtype=torch.float64) ** 2) @ R.T
+    gate = 1 / (1 + math.exp(-100 * ((1 - 1 / (1 + math.exp(9.0))) - 0.995)))
+    cov_ref = (2.0 * gate) ** 2 * Sig @ Sig.T
+    cov = (moved.T @ moved) / moved.shape[0]
+    assert float((cov - cov_ref).norm() / cov_ref.norm()) < 0.06 and float(moved.mean(0).norm()) < 0.02 * math.sqrt(float(cov_ref.trace()))
+
+
+def test_mcmc_trainer_relocates_and_grows(dev):
+    from mi3dgs import strategy_mcmc, trainer
+    sc = small_scene(n=1000, seed=61, big=True, width=96, height=64, n_views=4, fx=90.0)
+    sc.params["opacities"][:200] = -8.0               # dead: sigmoid < 0.005
+    g = sc.to(dev)
+    imgs = torch.rand(4, 64, 96, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    cfg = trainer.TrainConfig(max_steps=100, sh_degree_interval=1)
+    tr = strategy_mcmc.MCMCTrainer(g.params, g.viewmats, g.Ks, imgs, 96, 64, cfg,
+                                   strategy_mcmc.MCMCConfig(cap_max=1200, refine_start_iter=-1, refine_every=5,
+                                                            refine_stop_iter=100))
+    before_means = tr.model.p("means").clone()
+    n_rel = tr.relocate()
+    assert n_rel == 200
+    op = torch.sigmoid(tr.model.p("opacities"))
+    assert float(op.min()) >= 0.005 - 1e-6                          # nothing dead any more
+    moved = (tr.model.p("means")[:200] - before_means[:200]).norm(dim=1)
+    assert float(moved.min()) > 0                                   # teleported onto live Gaussians
+    same = (tr.model.p("means")[:200, None, :] == before_means[None, 200:, :]).all(-1).any(1)
+    assert bool(same.all())                                          # bit-exact copies of live positions
+    n_new = tr.add_new()
+    assert n_new == 50 and tr.model.n == 1050                       # +5 %
+    assert float(tr.model.state("means", "m")[1000:].abs().max()) == 0
+    for s in range(12):
+        tr.step(s % 4)
+    assert tr.model.n == 1200                                       # capped at cap_max
+    assert all(torch.isfinite(tr.model.p(k)).all() for k in trainer.GROUPS)
