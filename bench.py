@@ -340,7 +340,9 @@ def main():
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured offline with rocprofv3 --pmc
             if os.path.isfile(pmc):
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                # measured on the default workload only; tags like "rs_scatter/isect" map to the kernel name
+                if args.scene == "garden" and not args.n:
+                    traffic = json.load(open(pmc)).get(dom.split("/")[0], {}).get("hbm_bytes_per_launch")
             common = dict(kernel=dom, traffic=traffic, us_per_launch=stages[dom]["us_per_launch"],
                           launches_per_step=stages[dom]["launches_per_step"], alg_bytes_per_launch=alg[dom],
                           alg_GBps=stages[dom]["alg_GBps"], hbm_frac=stages[dom]["alg_GBps"] / HBM_PEAK_GBS)
