@@ -132,6 +132,10 @@ int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int
 size_t mi3dgs_sort_workspace_bytes(long long n);
 int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits, void* workspace,
                           size_t workspace_bytes, void* stream); /* stable, ascending, in place */
+/* A/B switch: 0 = classic radix passes (histogram + 3-kernel scan + scatter), 1 = onesweep
+ * (one histogram kernel for all passes, one chained-look-back kernel per pass), 2 = onesweep
+ * up to 4 M keys, classic above (the default; see binning.hip for the measurements). */
+int mi3dgs_debug_set_sort_mode(int mode);
 size_t mi3dgs_scan_workspace_bytes(long long n);
 int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long long n,
                               uint32_t* total_dev /* nullable */, void* workspace,

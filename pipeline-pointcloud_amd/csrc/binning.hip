@@ -224,10 +224,168 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     }
 }
 
+// ---- onesweep variant: one upfront kernel builds the digit histograms of ALL passes (the
+// digits of a key do not depend on its position), then each pass is ONE kernel: tiles chain
+// their per-digit prefixes with decoupled look-back instead of a separate histogram kernel plus
+// a three-kernel scan.  The 2 M-key depth sort was launch-latency bound at 5 launches per pass.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, single-word granule form):
+//   status[tile][digit] is ONE 64-bit word {epoch:30 | flag:2 | value:32} written and read
+//   with relaxed agent-scope atomics (sc1: bypasses the non-coherent L1, served by L2/memory),
+//   so there is no payload/flag ordering to get wrong; flag 1 = this tile's own count,
+//   2 = inclusive prefix.  Words whose epoch differs from the pass's epoch are "not yet".
+//   Tile ids are handed out by an atomic counter, so every predecessor of a tile belongs to a
+//   workgroup that has already started: the chain always resolves, whatever the residency.
+//   Every spin is bounded; a timeout raises *err and lets the grid drain.
+constexpr int OS_MAX_PASSES = 4;
+constexpr unsigned OS_SPIN_LIMIT = 1u << 24;
+
+__global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ n_ptr, uint32_t cap, int passes,
+                                                             int per, int nbits, uint32_t* __restrict__ ghist /*[passes][256]*/) {
+    __shared__ uint32_t h[OS_MAX_PASSES][256];
+    uint32_t n = live_count(n_ptr, cap);
+    uint32_t base = blockIdx.x * RS_TILE;
+    if (base >= n) return;
+#pragma unroll
+    for (int p = 0; p < OS_MAX_PASSES; p++) h[p][threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+        if (idx < n) {
+            uint32_t k = keys[idx];
+            int shift = 0;
+            for (int p = 0; p < passes; p++) {
+                int bits = (shift + per <= nbits) ? per : (nbits - shift);
+                atomicAdd(&h[p][(k >> shift) & ((1u << bits) - 1u)], 1u);
+                shift += bits;
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; p++) {
+        uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
+    }
+}
+
+__device__ __forceinline__ unsigned long long os_pack(uint32_t epoch, uint32_t flag, uint32_t value) {
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned long long)value;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
+    const uint32_t* __restrict__ ghist_pass /*[256]*/, unsigned long long* status /*[tiles][256]*/,
+    uint32_t* tile_counter, uint32_t epoch, uint32_t* err) {
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t delta[256];
+    __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t s_tile;
+    uint32_t n = live_count(n_ptr, cap);
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+#pragma unroll
+    for (int i = 0; i < 4; i++) cnt[i][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    uint32_t block_base = tile * RS_TILE;
+    if (block_base >= n) return;                      // later tiles are empty too: nobody waits on this one
+    int w = threadIdx.x >> 6, lane = lane_id();
+    uint32_t wbase = block_base + w * RS_WAVE_TILE;
+    uint32_t key[RS_ITEMS], loc[RS_ITEMS];
+    unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        uint32_t idx = wbase + r * 64 + lane;
+        bool valid = idx < n;
+        uint32_t k = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        uint32_t d = (k >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (d >> b) & 1u;
+            unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t rank = __popcll(peers & lt_mask);
+        uint32_t npeers = __popcll(peers);
+        uint32_t pre = valid ? cnt[w][d] : 0;
+        if (valid && rank == npeers - 1) cnt[w][d] = pre + npeers;
+        key[r] = k;
+        loc[r] = pre + rank;
+    }
+    __syncthreads();
+    uint32_t tot;
+    {
+        // thread d owns digit d: publish the tile's count, look back, publish the inclusive prefix
+        const uint32_t d = threadIdx.x;
+        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+        uint32_t mine = c0 + c1 + c2 + c3;
+        unsigned long long* my_status = status + (size_t)tile * 256 + d;
+        __hip_atomic_store(my_status, os_pack(epoch, tile == 0 ? 2u : 1u, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            uint32_t p = tile - 1;
+            while (true) {
+                const unsigned long long* ps = status + (size_t)p * 256 + d;
+                unsigned long long wv;
+                unsigned spins = 0;
+                while (true) {
+                    wv = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(wv >> 34) == epoch && ((wv >> 32) & 3ull) != 0ull) break;
+                    if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 1u); wv = os_pack(epoch, 2u, 0u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                excl += (uint32_t)wv;
+                if (((wv >> 32) & 3ull) == 2ull || p == 0) break;
+                p--;
+            }
+            __hip_atomic_store(my_status, os_pack(epoch, 2u, excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // digit base = exclusive scan of the global histogram; local start = exclusive scan of this tile's counts
+        uint32_t t2;
+        uint32_t dbase = block_excl_scan_u32(ghist_pass[d], &t2, lds4);
+        uint32_t lstart = block_excl_scan_u32(mine, &tot, lds4);
+        cnt[0][d] = lstart; cnt[1][d] = lstart + c0; cnt[2][d] = lstart + c0 + c1; cnt[3][d] = lstart + c0 + c1 + c2;
+        delta[d] = dbase + excl - lstart;                                 // global = local slot + delta[digit]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        uint32_t idx = wbase + r * 64 + lane;
+        if (idx < n) {
+            uint32_t d = (key[r] >> shift) & mask;
+            uint32_t slot = cnt[w][d] + loc[r];
+            skey[slot] = key[r];
+            sval[slot] = vals_in[idx];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tot; j += RS_THREADS) {
+        uint32_t k = skey[j];
+        uint32_t pos = j + delta[(k >> shift) & mask];
+        keys_out[pos] = k;
+        vals_out[pos] = sval[j];
+    }
+}
+
+// 0 = classic (histogram + 3-kernel scan + scatter per pass), 1 = onesweep, 2 = by size (default).
+// Measured on MI355X: onesweep wins while the sort is launch-latency bound (2 M keys, 4 passes:
+// 216 -> 178 us) and loses on large sorts (15 M keys, 2 passes: 350 -> 429 us; the look-back
+// chains are dependent sc1 loads served by L2, several hundred cycles each).
+int g_sort_mode = 2;
+constexpr uint32_t OS_MAX_KEYS = 4u << 20;
+
+// u32 words of scratch: classic needs the digit-major histogram + its scan scratch, onesweep the
+// global histograms, counters, error word and the 64-bit status table
 size_t rs_tmp_u32(uint32_t cap) {
     uint32_t B = mi_div_up(cap, RS_TILE);
     size_t hist = (size_t)256 * B;
-    return hist + mi_div_up(hist, SCAN_TILE) + 16;
+    size_t classic = hist + mi_div_up(hist, SCAN_TILE) + 16;
+    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + 2 * hist + 16;
+    return classic > onesweep ? classic : onesweep;
 }
 
 // LSD radix sort of (key,val) u32 pairs on bits [0, nbits).  Result ends up in (keys_a, vals_a)
@@ -247,13 +405,36 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     *result_in_b = 0;
     if (cap == 0 || nbits <= 0) return 0;
     uint32_t B = mi_div_up(cap, RS_TILE);
-    uint32_t* hist = tmp;
-    uint32_t* scan_tmp = tmp + (size_t)256 * B;
     int passes = (nbits + 7) / 8;
     // spread the bits evenly over the passes (13 bits -> 7 + 6)
     int per = (nbits + passes - 1) / passes;
     int shift = 0;
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
+    if (g_sort_mode == 1 || (g_sort_mode == 2 && cap <= OS_MAX_KEYS)) {
+        // layout: ghist[4][256] | counters[8] err[1] pad[7] | status[B][256] u64
+        uint32_t* ghist = tmp;
+        uint32_t* counters = tmp + OS_MAX_PASSES * 256;
+        uint32_t* err = counters + 8;
+        unsigned long long* status = reinterpret_cast<unsigned long long*>(tmp + OS_MAX_PASSES * 256 + 16);
+        // one clear per sort call: histograms, counters, and the status table (epochs 1..passes)
+        MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B) * sizeof(uint32_t), st));
+        MI_LAUNCH(htag, os_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist);
+        for (int p = 0; p < passes; p++) {
+            int bits = (shift + per <= nbits) ? per : (nbits - shift);
+            uint32_t mask = (1u << bits) - 1u;
+            MI_LAUNCH(ctag, os_pass_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n_ptr, cap, shift, mask,
+                      ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
+            uint32_t* t;
+            t = ki; ki = ko; ko = t;
+            t = vi; vi = vo; vo = t;
+            shift += bits;
+        }
+        MI_LAUNCH_CHECK();
+        *result_in_b = passes & 1;
+        return 0;
+    }
+    uint32_t* hist = tmp;
+    uint32_t* scan_tmp = tmp + (size_t)256 * B;
     for (int p = 0; p < passes; p++) {
         int bits = (shift + per <= nbits) ? per : (nbits - shift);
         uint32_t mask = (1u << bits) - 1u;
@@ -730,4 +911,10 @@ extern "C" int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long
     MI_REQUIRE(n >= 0 && n < (1ll << 31), "scan: bad n");
     MI_REQUIRE(n == 0 || (workspace && workspace_bytes >= mi3dgs_scan_workspace_bytes(n)), "scan: workspace too small");
     return scan_exclusive_u32(in, out, (uint32_t)n, (uint32_t*)workspace, total_dev, (hipStream_t)stream);
+}
+
+// A/B switch for benchmarking and tests: 0 = classic multi-kernel passes, 1 = onesweep (default).
+extern "C" int mi3dgs_debug_set_sort_mode(int mode) {
+    g_sort_mode = (mode < 0 || mode > 2) ? 2 : mode;
+    return 0;
 }

@@ -29,10 +29,12 @@ def test_scan_exclusive_bit_exact(dev, n):
     assert int(total.item()) == int(x.sum())
 
 
+@pytest.mark.parametrize("mode", [0, 1])          # classic multi-kernel passes / onesweep look-back
 @pytest.mark.parametrize("n,nbits", [(1, 32), (64, 32), (4096, 32), (5000, 13), (100_003, 32), (1_500_000, 13),
                                      (300_000, 7)])
-def test_radix_sort_stable_bit_exact(dev, n, nbits):
+def test_radix_sort_stable_bit_exact(dev, n, nbits, mode):
     ops = _ops()
+    ops._lib.lib().mi3dgs_debug_set_sort_mode(mode)
     g = torch.Generator().manual_seed(n)
     hi = (1 << nbits) - 1
     # many duplicates so that stability is exercised
@@ -43,6 +45,7 @@ def test_radix_sort_stable_bit_exact(dev, n, nbits):
     k = keys.to(torch.int32).to(dev) if nbits < 32 else (keys & 0xFFFFFFFF).to(torch.int64).to(torch.int32).to(dev)
     v = vals.to(dev)
     ops.sort_pairs_u32(k, v, nbits)
+    ops._lib.lib().mi3dgs_debug_set_sort_mode(2)
     order = np.argsort(keys.numpy(), kind="stable")
     assert np.array_equal(v.cpu().numpy(), vals.numpy()[order])
     assert np.array_equal(k.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys.numpy()[order])
