@@ -1,0 +1,78 @@
+"""Oracle for the reference's PLY post-processing.  TEST INFRASTRUCTURE ONLY.
+
+numpy / scipy restatement of
+  source/container/src/pipeline/post_processing/rotate_splat.py:90-178   rotate_gaussians,
+      rotate_sh_coefficients, :245-276 create_rotation_matrix, :278-310 parse_rotation_spec,
+      :351-356 sequential application
+  source/container/src/pipeline/post_processing/mirror_splat.py:33-124   mirror_ply
+The reference modules themselves import `plyfile`, which is absent from this image, so they
+cannot be imported here; their array arithmetic is restated 1:1 (scipy is present, so the very
+same `Rotation` calls are used).  PINNED by nothing but the reference source: it ships no
+fixtures for these scripts.
+"""
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+
+def create_rotation_matrix(axis, angle_degrees):
+    a = np.radians(angle_degrees)
+    c, s = np.cos(a), np.sin(a)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == "y":
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def parse_rotation_spec(spec):
+    out = []
+    for part in (spec or "").split(","):
+        if ":" in part:
+            axis, angle = part.split(":")
+            axis = axis.strip().lower()
+            if axis in ("x", "y", "z"):
+                try:
+                    out.append((axis, float(angle.strip())))
+                except ValueError:
+                    pass
+    return out
+
+
+def rotate_sh_coefficients(sh_dc, sh_rest, R):
+    """rotate_splat.py:141-178: only f_rest[:, 0:9], three at a time, times R^T."""
+    rest = sh_rest.copy()
+    if rest.shape[1] >= 9:
+        for i in range(0, 9, 3):
+            rest[:, i:i + 3] = np.dot(sh_rest[:, i:i + 3], R.T)
+    return sh_dc.copy(), rest
+
+
+def rotate_gaussians(positions, rotations_wxyz, sh_dc, sh_rest, R):
+    """rotate_splat.py:90-139 (the per-Gaussian scipy loop, vectorised: same composition)."""
+    pos = np.dot(positions, R.T)
+    rot = Rotation.from_matrix(R)
+    existing = Rotation.from_quat(np.column_stack([rotations_wxyz[:, 1], rotations_wxyz[:, 2], rotations_wxyz[:, 3],
+                                                   rotations_wxyz[:, 0]]))
+    q = (rot * existing).as_quat()
+    quat = np.column_stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]])
+    dc, rest = rotate_sh_coefficients(sh_dc, sh_rest, R)
+    return pos, quat, dc, rest
+
+
+def mirror(positions, rotations_wxyz, sh_rest, axis):
+    """mirror_splat.py:52-124."""
+    M = np.eye(3)
+    M["xyz".index(axis), "xyz".index(axis)] = -1
+    pos = np.dot(positions, M)
+    rm = Rotation.from_quat(np.column_stack([rotations_wxyz[:, 1], rotations_wxyz[:, 2], rotations_wxyz[:, 3],
+                                             rotations_wxyz[:, 0]])).as_matrix()
+    mr = np.einsum("ij,njk->nik", M, rm)
+    mask = np.linalg.det(mr) < 0.0
+    mr[mask, :, 0] *= -1.0
+    q = Rotation.from_matrix(mr).as_quat()
+    quat = np.column_stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]])
+    rest = sh_rest.copy()
+    if rest.shape[1] >= 9:
+        for i in range(0, 9, 3):
+            rest[:, i:i + 3] = np.dot(rest[:, i:i + 3], M)
+    return pos, quat, rest
