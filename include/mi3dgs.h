@@ -210,6 +210,22 @@ int mi3dgs_mcmc_regularise(int N, const float* opacities_logit, const float* sca
                            float opacity_reg, float scale_reg, float* v_opacities, float* v_scales,
                            void* stream);
 
+/* ---- input side ----------------------------------------------------
+ * knn: exact k nearest neighbours (k <= 4, the point itself excluded by index) of points[n,3];
+ * out_d2[n,k] ascending squared distances (+inf where fewer than k other points exist),
+ * out_idx_opt[n,k] (nullable) their indices (-1 where missing).  Replaces the sklearn
+ * NearestNeighbors call of splatfacto's / simple_trainer's scale initialisation, reached through
+ * reference main.py:1271 and :1328.  No host synchronisation.
+ * image_downscale_area: cv2.resize(..., INTER_AREA) of an [H,W,channels] u8 image to
+ * [out_height,out_width,channels], u8 (round to nearest even) or f32 in [0,1]
+ * (reference main.py:419-481 ensure_downscaled_images).  image_u8_to_f32: dst = src * scale. */
+size_t mi3dgs_knn_workspace_bytes(long long n);
+int mi3dgs_knn(long long n, const float* points, int k, float* out_d2, int32_t* out_idx_opt,
+               void* workspace, size_t workspace_bytes, void* stream);
+int mi3dgs_image_downscale_area(const uint8_t* src, int height, int width, int channels, void* dst,
+                                int out_height, int out_width, int dst_is_f32, void* stream);
+int mi3dgs_image_u8_to_f32(const uint8_t* src, long long n, float* dst, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,48 @@ def mirror(positions, rotations_wxyz, sh_rest, axis):
         for i in range(0, 9, 3):
             rest[:, i:i + 3] = np.dot(rest[:, i:i + 3], M)
     return pos, quat, rest
+
+
+# ------------------------------------------------------------------ input side
+def knn_sq_dists(points, k=3):
+    """Squared distances to the k nearest OTHER points, ascending, float64 brute force; rows with
+    fewer than k other points are padded with +inf.  What splatfacto's `k_nearest_sklearn`
+    (NearestNeighbors(k+1), first column dropped) and gsplat's `knn(points, 4)[:, 1:]` return,
+    squared; pinned against scikit-learn itself in tests/test_input_side_cpu.py."""
+    p = np.asarray(points, dtype=np.float64)
+    n = p.shape[0]
+    out = np.full((n, k), np.inf)
+    for s in range(0, n, 2048):
+        d = ((p[s:s + 2048, None, :] - p[None, :, :]) ** 2).sum(-1)
+        d[np.arange(d.shape[0]), np.arange(s, s + d.shape[0])] = np.inf      # the point itself, by index
+        d.sort(axis=1)
+        m = min(k, n - 1)
+        out[s:s + 2048, :m] = d[:, :m]
+    return out
+
+
+def area_downscale(img_u8, out_h, out_w, as_float=False):
+    """cv2.resize(..., interpolation=INTER_AREA) as defined: every output pixel is the mean of the
+    source area [x W/w, (x+1) W/w) x [y H/h, (y+1) H/h) with fractional coverage weights
+    (reference main.py:472-475), the weights of OpenCV's computeResizeAreaTab.  cv2 is absent from
+    this image; pinned by PIL's BOX filter for integer factors (where both are the block mean; PIL
+    samples by pixel centres otherwise) and by the closed form for a ramp at fractional factors."""
+    a = np.asarray(img_u8, dtype=np.float64)
+    H, W = a.shape[:2]
+
+    def weights(n_in, n_out):
+        m = np.zeros((n_out, n_in))
+        s = n_in / n_out
+        for o in range(n_out):
+            f0, f1 = o * s, min((o + 1) * s, n_in)
+            for i in range(int(np.floor(f0)), min(int(np.ceil(f1)), n_in)):
+                m[o, i] = min(i + 1, f1) - max(i, f0)
+            m[o] /= (f1 - f0)
+        return m
+
+    wy, wx = weights(H, out_h), weights(W, out_w)
+    r = np.tensordot(wy, a, axes=(1, 0))                       # [y, X, c]  (rows first, then columns:
+    r = np.tensordot(r, wx, axes=(1, 1)).transpose(0, 2, 1)    # [y, x, c]   two small products, not one 5-index sum)
+    if as_float:
+        return r / 255.0
+    return np.clip(np.rint(r), 0, 255).astype(np.uint8)

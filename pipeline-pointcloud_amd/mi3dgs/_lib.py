@@ -58,6 +58,10 @@ _SIGNATURES = {
     "mi3dgs_mcmc_relocation": (_i, [_i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_mcmc_inject_noise": (_i, [_i, _f, _f, _f, _f, _fl, _u32, _f]),
     "mi3dgs_mcmc_regularise": (_i, [_i, _f, _f, _fl, _fl, _f, _f, _f]),
+    "mi3dgs_knn_workspace_bytes": (_sz, [_ll]),
+    "mi3dgs_knn": (_i, [_ll, _f, _i, _f, _f, _f, _sz, _f]),
+    "mi3dgs_image_downscale_area": (_i, [_f, _i, _i, _i, _f, _i, _i, _i, _f]),
+    "mi3dgs_image_u8_to_f32": (_i, [_f, _ll, _f, _fl, _f]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

@@ -157,7 +157,7 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     n_pts = ds.points.shape[0]
     say(f"dataset: {len(ds.train_idx)} train / {len(ds.eval_idx)} eval images {ds.width}x{ds.height}, {n_pts} SfM points")
     params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb)
-    imgs = ds.load_images(ds.train_idx, dev)
+    imgs = ds.load_images(ds.train_idx, dev, as_u8=True)       # device image cache (uint8)
     vm, ks = ds.viewmats[ds.train_idx].to(dev), ds.Ks[ds.train_idx].to(dev)
     if strategy == "mcmc":
         from .strategy_mcmc import MCMCConfig, MCMCTrainer

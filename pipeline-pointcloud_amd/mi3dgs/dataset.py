@@ -45,16 +45,26 @@ class Dataset:
     train_idx: List[int] = field(default_factory=list)
     eval_idx: List[int] = field(default_factory=list)
 
-    def load_images(self, idx: List[int], device) -> torch.Tensor:
-        """[len(idx),H,W,3] float32 in [0,1] on `device` (decoded on the host, one PCIe trip)."""
+    def load_images(self, idx: List[int], device, as_u8: bool = False) -> torch.Tensor:
+        """[len(idx),H,W,3] on `device`: float32 in [0,1], or uint8 (`as_u8`, the device image
+        cache: 500 4K frames are 12 GB of the 288).  Files are decoded on the host and cross PCIe
+        once as uint8; a file larger than (width, height) is area-averaged down ON the GPU
+        (ops.image_downscale_area = the INTER_AREA pre-pass of main.py:419-481, without the
+        `images_{k}/` directory)."""
         from PIL import Image
-        out = torch.empty(len(idx), self.height, self.width, 3, dtype=torch.float32, device=device)
+        from . import ops
+        out = torch.empty(len(idx), self.height, self.width, 3, dtype=torch.uint8 if as_u8 else torch.float32,
+                          device=device)
         for j, i in enumerate(idx):
             im = Image.open(self.image_paths[i]).convert("RGB")
+            a = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).to(device)
             if im.size != (self.width, self.height):
-                im = im.resize((self.width, self.height), Image.BOX)
-            a = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy())
-            out[j] = a.to(device).float().div_(255.0)
+                if im.size[0] < self.width or im.size[1] < self.height:
+                    raise ValueError(f"{self.image_paths[i]}: {im.size} is smaller than the camera's "
+                                     f"{(self.width, self.height)}")
+                out[j] = ops.image_downscale_area(a, self.height, self.width, as_float=not as_u8)
+            else:
+                out[j] = a if as_u8 else a.float().div_(255.0)
         return out
 
     def denormalise(self, means: torch.Tensor, log_scales: torch.Tensor):
@@ -114,25 +124,23 @@ def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: in
                    float(scale), train_idx, eval_idx)
 
 
-def knn_mean_sq_dist(points: torch.Tensor, k: int = 3, chunk: int = 4096) -> torch.Tensor:
-    """Mean squared distance to the k nearest neighbours (excluding the point itself).
-    Chunked brute force on whatever device `points` lives on."""
-    P = points.shape[0]
-    out = torch.empty(P, dtype=points.dtype, device=points.device)
-    kk = min(k + 1, P)
-    for s in range(0, P, chunk):
-        d2 = torch.cdist(points[s:s + chunk], points).pow_(2)
-        v = torch.topk(d2, kk, dim=1, largest=False).values[:, 1:]
-        out[s:s + chunk] = v.mean(1) if v.numel() else 0.0
-    return out
+def knn_mean_sq_dist(points: torch.Tensor, k: int = 3) -> torch.Tensor:
+    """Mean squared distance to the k nearest neighbours (excluding the point itself): the HIP
+    grid search `mi3dgs_knn` (csrc/spatial.hip).  GPU tensors only."""
+    from . import ops
+    d2 = ops.knn(points.float().contiguous(), k)
+    ok = torch.isfinite(d2)                               # fewer than k other points: mean of what exists
+    cnt = ok.sum(1).clamp(min=1)
+    return torch.where(ok, d2, torch.zeros_like(d2)).sum(1) / cnt
 
 
 def init_gaussians(points: torch.Tensor, rgb_u8: torch.Tensor, init_opacity: float = 0.1, init_scale: float = 1.0,
-                   seed: int = 42) -> Dict[str, torch.Tensor]:
-    """Initial parameters in the checkpoint schema (post_processing/gsplat_pt_to_ply.py:45-73)."""
+                   seed: int = 42, knn_d2: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Initial parameters in the checkpoint schema (post_processing/gsplat_pt_to_ply.py:45-73).
+    `knn_d2` (mean squared 3-NN distance per point) is computed on the GPU unless handed in."""
     dev = points.device
     P = points.shape[0]
-    d2 = knn_mean_sq_dist(points, 3)
+    d2 = knn_mean_sq_dist(points, 3) if knn_d2 is None else knn_d2.to(dev)
     scales = torch.log(torch.sqrt(d2).clamp_min(1e-7) * init_scale)[:, None].repeat(1, 3)
     g = torch.Generator().manual_seed(seed)
     quats = torch.rand(P, 4, generator=g).to(dev)
@@ -141,3 +149,38 @@ def init_gaussians(points: torch.Tensor, rgb_u8: torch.Tensor, init_opacity: flo
     shN = torch.zeros(P, 15, 3, device=dev)
     return dict(means=points.float().contiguous(), quats=quats.float().contiguous(), scales=scales.float().contiguous(),
                 opacities=opac.float(), sh0=sh0.float().contiguous(), shN=shN)
+
+
+def ensure_downscaled_images(images_dir: str, downscale_factor, device=None) -> int:
+    """`ensure_downscaled_images` of the reference (source/container/src/main.py:419-481): creates
+    `images_{k}/` beside `images_dir` with every .jpg/.jpeg/.png area-averaged to
+    (max(1, int(w/k)), max(1, int(h/k))), skipping the work when the directory is already
+    complete.  The resize runs on the GPU; returns the number of files written."""
+    from PIL import Image
+    from . import ops
+    try:
+        k = int(str(downscale_factor))
+    except (TypeError, ValueError):
+        k = 1
+    if k <= 1 or not os.path.isdir(images_dir):
+        return 0
+    target = os.path.join(os.path.dirname(images_dir), f"images_{k}")
+    os.makedirs(target, exist_ok=True)
+    exts = (".jpg", ".jpeg", ".png")
+    files = sorted(f for f in os.listdir(images_dir) if f.lower().endswith(exts))
+    if not files or len([f for f in os.listdir(target) if f.lower().endswith(exts)]) == len(files):
+        return 0
+    dev = torch.device(device if device is not None else "cuda")
+    n = 0
+    for f in files:
+        im = Image.open(os.path.join(images_dir, f))
+        if im.mode not in ("L", "RGB", "RGBA"):
+            im = im.convert("RGB")
+        a = np.asarray(im, dtype=np.uint8)
+        a = a[:, :, None] if a.ndim == 2 else a
+        h, w = a.shape[:2]
+        out = ops.image_downscale_area(torch.from_numpy(a.copy()).to(dev), max(1, int(h / k)), max(1, int(w / k)))
+        o = out.cpu().numpy()
+        Image.fromarray(o[:, :, 0] if o.shape[2] == 1 else o).save(os.path.join(target, f))
+        n += 1
+    return n

@@ -292,6 +292,42 @@ def scan_exclusive_u32(x: torch.Tensor, out: Optional[torch.Tensor] = None, tota
     return out
 
 
+# ------------------------------------------------------------------------- input side
+def knn(points: torch.Tensor, k: int = 3, want_idx: bool = False):
+    """Exact k-NN of points[n,3] (float32, on the GPU), the point itself excluded: squared
+    distances [n,k] ascending (+inf where fewer than k other points exist) and, on request, the
+    neighbour indices [n,k] (int32, -1 where missing)."""
+    _chk(points, "points", (points.shape[0], 3))
+    n = points.shape[0]
+    d2 = torch.empty(n, k, dtype=torch.float32, device=points.device)
+    idx = torch.empty(n, k, dtype=torch.int32, device=points.device) if want_idx else None
+    nbytes = _lib.lib().mi3dgs_knn_workspace_bytes(n)
+    ws = workspace(nbytes, points.device, "knn")
+    _lib.call("mi3dgs_knn", n, _p(points), int(k), _p(d2), _p(idx), _p(ws), ws.numel(), _stream(points.device))
+    return (d2, idx) if want_idx else d2
+
+
+def image_downscale_area(img_u8: torch.Tensor, out_h: int, out_w: int, as_float: bool = False) -> torch.Tensor:
+    """INTER_AREA resize of an [H,W,Ch] uint8 image on the GPU -> [out_h,out_w,Ch] uint8, or float32 in [0,1]."""
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or not img_u8.is_cuda or not img_u8.is_contiguous():
+        raise ValueError("image_downscale_area: expected a contiguous [H,W,Ch] uint8 tensor on the GPU")
+    H, W, Ch = img_u8.shape
+    out = torch.empty(out_h, out_w, Ch, dtype=torch.float32 if as_float else torch.uint8, device=img_u8.device)
+    _lib.call("mi3dgs_image_downscale_area", _p(img_u8), H, W, Ch, _p(out), int(out_h), int(out_w), int(as_float),
+              _stream(img_u8.device))
+    return out
+
+
+def image_u8_to_f32(img_u8: torch.Tensor, out: Optional[torch.Tensor] = None, scale: float = 1.0 / 255.0):
+    """uint8 image (any shape, GPU) -> float32 * scale: the device image cache keeps u8, a step reads f32."""
+    if img_u8.dtype != torch.uint8 or not img_u8.is_cuda or not img_u8.is_contiguous():
+        raise ValueError("image_u8_to_f32: expected a contiguous uint8 tensor on the GPU")
+    if out is None:
+        out = torch.empty(img_u8.shape, dtype=torch.float32, device=img_u8.device)
+    _lib.call("mi3dgs_image_u8_to_f32", _p(img_u8), img_u8.numel(), _p(out), float(scale), _stream(img_u8.device))
+    return out
+
+
 # --------------------------------------------------------------- gsplat-shaped operator
 class _Rasterization(torch.autograd.Function):
     """project -> bin -> rasterize as one differentiable op (backward = rasterize_bwd -> project_bwd)."""

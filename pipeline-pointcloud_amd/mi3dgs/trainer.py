@@ -121,7 +121,11 @@ class Trainer:
         dev = self.model.device
         self.device = dev
         self.viewmats, self.Ks = viewmats.to(dev).contiguous(), Ks.to(dev).contiguous()
-        self.images = images          # [V,H,W,3] float32 in [0,1] on the device
+        # [V,H,W,3] on the device: float32 in [0,1], or the uint8 image cache (a quarter of the HBM;
+        # the step converts its one target with ops.image_u8_to_f32)
+        self.images = images
+        self._gt_f32 = (torch.empty(1, int(height), int(width), 3, dtype=torch.float32, device=dev)
+                        if images is not None and images.dtype == torch.uint8 else None)
         self.W, self.H = int(width), int(height)
         self.step_count = 0
         cap = self.model.capacity
@@ -187,6 +191,8 @@ class Trainer:
         viewmat = self.viewmats[view_index: view_index + 1]
         K = self.Ks[view_index: view_index + 1]
         gt = self.images[view_index: view_index + 1]
+        if self._gt_f32 is not None:
+            gt = ops.image_u8_to_f32(gt, self._gt_f32)
         sd = self.sh_degree_now()
         bg = None
         if c.random_background:

@@ -1,0 +1,127 @@
+"""Input-side kernels: exact k-NN, INTER_AREA downscale, uint8 image cache."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import small_scene
+from mi3dgs import dataset, ops, trainer
+from oracle import post_oracle as PO
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _clouds():
+    g = torch.Generator().manual_seed(0)
+    uni = torch.rand(5000, 3, generator=g)
+    sfm = torch.cat([torch.randn(4000, 3, generator=g), torch.randn(1500, 3, generator=g) * 0.02 + 2.0,
+                     torch.randn(40, 3, generator=g) * 300.0])                       # clusters + far outliers
+    flat = torch.cat([torch.rand(3000, 2, generator=g), torch.zeros(3000, 1)], 1)    # a plane
+    line = torch.cat([torch.rand(2000, 1, generator=g), torch.zeros(2000, 2)], 1) + 5.0
+    dup = torch.rand(700, 3, generator=g).repeat(3, 1)                                # every point three times
+    same = torch.ones(300, 3) * 0.25                                                 # zero extent
+    offset = torch.rand(3000, 3, generator=g) * 1e-2 + 1000.0                        # tight cloud far from the origin
+    shell = torch.nn.functional.normalize(torch.randn(8000, 3, generator=g), dim=1) * 3.0   # a surface: most cells empty
+    return dict(uniform=uni, sfm=sfm, plane=flat, line=line, duplicates=dup, identical=same, offset=offset, shell=shell)
+
+
+@pytest.mark.parametrize("name", list(_clouds()))
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_knn_equals_brute_force(name, k):
+    pts = _clouds()[name]
+    want = PO.knn_sq_dists(pts.numpy(), k)
+    d2, idx = ops.knn(pts.to(DEV), k, want_idx=True)
+    d2, idx = d2.cpu().double().numpy(), idx.cpu().long().numpy()
+    assert np.allclose(d2, want, rtol=2e-6, atol=1e-12)
+    assert np.all(np.diff(d2, axis=1) >= 0)
+    # the reported neighbours are other points, distinct, and at the reported distances
+    n = pts.shape[0]
+    assert np.all(idx != np.arange(n)[:, None]) and np.all((idx >= 0) & (idx < n))
+    if k > 1:
+        assert np.all(np.sort(idx, 1)[:, 1:] != np.sort(idx, 1)[:, :-1])
+    p = pts.double().numpy()
+    assert np.allclose(((p[idx] - p[:, None, :]) ** 2).sum(-1), d2, rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 65])
+def test_knn_tiny_inputs(n):
+    pts = torch.rand(n, 3, generator=torch.Generator().manual_seed(n))
+    d2, idx = ops.knn(pts.to(DEV), 3, want_idx=True)
+    want = PO.knn_sq_dists(pts.numpy(), 3)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(d2.cpu().numpy()), fin) and np.array_equal(idx.cpu().numpy() >= 0, fin)
+    assert np.allclose(d2.cpu().numpy()[fin], want[fin], rtol=2e-6)
+    assert ops.knn(torch.empty(0, 3, device=DEV), 3).shape == (0, 3)
+    with pytest.raises(Exception, match="k must be"):
+        ops.knn(pts.to(DEV), 5)
+
+
+def test_knn_large_cloud_against_sampled_brute_force_and_sfm_scales():
+    g = torch.Generator().manual_seed(5)
+    n = 400_000
+    pts = torch.cat([torch.randn(n // 2, 3, generator=g) * torch.tensor([4.0, 4.0, 0.3]),
+                     torch.rand(n // 2, 3, generator=g) * 2 - 1]).to(DEV)
+    d2 = ops.knn(pts, 3)
+    sel = torch.randperm(n, generator=g)[:2000].to(DEV)
+    d = torch.cdist(pts[sel].double(), pts.double()).pow(2)
+    d[torch.arange(2000, device=DEV), sel] = float("inf")
+    want = torch.topk(d, 3, dim=1, largest=False).values
+    assert torch.allclose(d2[sel].double(), want, rtol=2e-6, atol=1e-12)
+    P = dataset.init_gaussians(pts, torch.zeros(n, 3, dtype=torch.uint8))
+    assert torch.allclose(P["scales"][sel, 0].double(), torch.log(torch.sqrt(want.mean(1))), atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,out", [((36, 54, 3), (18, 27)), ((37, 53, 3), (18, 26)), ((1080, 1920, 3), (270, 480)),
+                                       ((101, 67, 3), (33, 22)), ((16, 16, 1), (1, 1)), ((20, 30, 4), (20, 30)),
+                                       ((9, 200, 3), (9, 66))])
+def test_area_downscale_equals_oracle(shape, out):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    t = torch.from_numpy(img).to(DEV)
+    got_u8 = ops.image_downscale_area(t, *out).cpu().numpy().astype(np.int32)
+    want_f = PO.area_downscale(img, *out, as_float=True)
+    got_f = ops.image_downscale_area(t, *out, as_float=True).cpu().numpy()
+    assert np.abs(got_f - want_f).max() < 2e-6
+    # uint8: equal except where the exact mean sits on a rounding boundary to float precision
+    want_u8 = PO.area_downscale(img, *out).astype(np.int32)
+    bad = got_u8 != want_u8
+    frac = np.abs((want_f * 255.0) % 1.0 - 0.5)
+    assert np.all(frac[bad] < 1e-3) and np.abs(got_u8 - want_u8).max() <= 1
+    with pytest.raises(Exception, match="larger"):
+        ops.image_downscale_area(t, shape[0] + 1, shape[1])
+
+
+def test_u8_image_cache_trains_like_the_float_targets():
+    sc = small_scene(n=1500, seed=21, width=96, height=64, n_views=3, fx=90.0).to(DEV)
+    imgs_u8 = (torch.rand(3, 64, 96, 3, generator=torch.Generator().manual_seed(1)) * 255).to(torch.uint8).to(DEV)
+    for n in (1, 2, 3, 5, 7, 64 * 96 * 3):                                         # ragged tails of the 4-wide kernel
+        flat = imgs_u8.reshape(-1)[:n].contiguous()
+        assert torch.equal(ops.image_u8_to_f32(flat), flat.float() * (1.0 / 255.0))
+    runs = []
+    for images in (imgs_u8, imgs_u8.float() * (1.0 / 255.0)):
+        tr = trainer.Trainer({k: v.clone() for k, v in sc.params.items()}, sc.viewmats, sc.Ks, images, 96, 64,
+                             trainer.TrainConfig(densify=False, fuse_adam=False))
+        losses = [tr.step(i % 3, want_loss=True) for i in range(6)]
+        runs.append((losses, tr.model.p("means").clone()))
+    # identical targets bit for bit (checked above); the steps differ only by float-atomic summation order
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and torch.allclose(runs[0][1], runs[1][1], atol=1e-5)
+
+
+def test_ensure_downscaled_images_and_device_resize_on_load(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    os.makedirs(tmp_path / "images")
+    src = {}
+    for i in range(3):
+        src[f"f{i}.png"] = rng.integers(0, 256, size=(45, 70, 3), dtype=np.uint8)
+        Image.fromarray(src[f"f{i}.png"]).save(tmp_path / "images" / f"f{i}.png")
+    assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "4") == 3
+    for name, a in src.items():
+        got = np.asarray(Image.open(tmp_path / "images_4" / name))
+        assert got.shape == (11, 17, 3)                                            # max(1, int(h / k)), int(w / k)
+        assert np.abs(got.astype(np.int32) - PO.area_downscale(a, 11, 17).astype(np.int32)).max() <= 1
+    assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "4") == 0     # already complete
+    assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "1") == 0
+    assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "abc") == 0

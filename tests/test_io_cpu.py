@@ -97,7 +97,11 @@ def test_sfm_initialisation():
     g = torch.Generator().manual_seed(0)
     pts = torch.rand(500, 3, generator=g)
     rgb = torch.randint(0, 255, (500, 3), generator=g, dtype=torch.uint8)
-    P = dataset.init_gaussians(pts, rgb)
+    # the k-NN itself is a HIP kernel (tests/test_gpu_input_side.py); here the oracle's distances go in
+    from oracle import post_oracle as PO
+    P = dataset.init_gaussians(pts, rgb, knn_d2=torch.from_numpy(PO.knn_sq_dists(pts.numpy(), 3).mean(1)).float())
+    with pytest.raises(ValueError, match="GPU"):
+        dataset.init_gaussians(pts, rgb)                   # no CPU path for the search
     d = torch.cdist(pts.double(), pts.double())
     ref = torch.log(torch.sqrt((torch.topk(d, 4, largest=False).values[:, 1:] ** 2).mean(1)))
     assert torch.allclose(P["scales"][:, 0].double(), ref, atol=1e-4) and torch.equal(P["scales"][:, 0], P["scales"][:, 2])
