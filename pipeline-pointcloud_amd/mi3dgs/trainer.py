@@ -60,6 +60,10 @@ class TrainConfig:
     max_gauss_ratio: float = 10.0
     scale_reg_every: int = 10
     random_background: bool = False
+    # splatfacto's coarse-to-fine schedule: train at 1/2^num_downscales of the resolution, doubling
+    # every `resolution_schedule` steps (nerfstudio defaults 2 and 3000; gsplat's trainer: 0)
+    num_downscales: int = 0
+    resolution_schedule: int = 3000
     antialiased: bool = False
     near_plane: float = 0.01
     far_plane: float = 1e10
@@ -127,6 +131,7 @@ class Trainer:
         self._gt_f32 = (torch.empty(1, int(height), int(width), 3, dtype=torch.float32, device=dev)
                         if images is not None and images.dtype == torch.uint8 else None)
         self.W, self.H = int(width), int(height)
+        self.W0, self.H0, self.Ks0, self._cur_d = self.W, self.H, self.Ks, 1
         self.step_count = 0
         cap = self.model.capacity
         self.radii = torch.empty(1, cap, 2, dtype=torch.int32, device=dev)
@@ -156,6 +161,42 @@ class Trainer:
             f |= ops.FLAG_ANTIALIASED
         return f
 
+    def downscale_now(self) -> int:
+        c = self.cfg
+        return 2 ** max(c.num_downscales - self.step_count // max(c.resolution_schedule, 1), 0)
+
+    def set_resolution(self, d: int) -> None:
+        """Train / render at 1/d of the full resolution: (W // d, H // d), intrinsics scaled by 1/d,
+        targets area-averaged over d x d blocks (nerfstudio: Cameras.rescale_output_resolution +
+        resize_image's box filter [UPSTREAM-UNVERIFIED]).  Re-allocates the per-pixel buffers."""
+        d = max(1, int(d))
+        if d == self._cur_d:
+            return
+        self._cur_d = d
+        self.W, self.H = max(1, self.W0 // d), max(1, self.H0 // d)
+        self.Ks = self.Ks0.clone()
+        self.Ks[:, :2, :] /= float(d)
+        dev = self.device
+        self.raster_out, self.loss_scratch = {}, {}
+        self.v_render = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
+        self.v_alphas = torch.zeros(1, self.H, self.W, 1, dtype=torch.float32, device=dev)
+        if self._gt_f32 is not None:
+            self._gt_f32 = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
+
+    def _target(self, view_index: int) -> torch.Tensor:
+        """[1,H,W,3] float32 target of the current resolution level."""
+        img, d = self.images[view_index], self._cur_d
+        if d > 1:
+            Hc, Wc = self.H * d, self.W * d                # nerfstudio's strided box filter drops the remainder
+            if (Hc, Wc) != (self.H0, self.W0):
+                img = img[:Hc, :Wc].contiguous()
+            if img.dtype == torch.uint8:
+                return ops.image_downscale_area(img, self.H, self.W, as_float=True)[None]
+            return img.view(self.H, d, self.W, d, 3).mean(dim=(1, 3))[None].contiguous()
+        if self._gt_f32 is not None:
+            return ops.image_u8_to_f32(img[None], self._gt_f32)
+        return img[None]
+
     def sh_degree_now(self) -> int:
         return min(self.step_count // self.cfg.sh_degree_interval, self.cfg.sh_degree)
 
@@ -178,7 +219,8 @@ class Trainer:
 
     @torch.no_grad()
     def render(self, viewmat: torch.Tensor, K: torch.Tensor, sh_degree: Optional[int] = None, background=None):
-        """Render one view: [1,H,W,3], [1,H,W,1].  (Outputs alias internal buffers.)"""
+        """Render one view at full resolution: [1,H,W,3], [1,H,W,1].  (Outputs alias internal buffers.)"""
+        self.set_resolution(1)
         sd = self.cfg.sh_degree if sh_degree is None else sh_degree
         _, _, _, render, alphas, _ = self._forward(viewmat.view(1, 4, 4), K.view(1, 3, 3), sd, background)
         return render, alphas
@@ -188,11 +230,10 @@ class Trainer:
     def step(self, view_index: int, want_loss: bool = False):
         c, m = self.cfg, self.model
         n = self._n()
+        self.set_resolution(self.downscale_now())
         viewmat = self.viewmats[view_index: view_index + 1]
         K = self.Ks[view_index: view_index + 1]
-        gt = self.images[view_index: view_index + 1]
-        if self._gt_f32 is not None:
-            gt = ops.image_u8_to_f32(gt, self._gt_f32)
+        gt = self._target(view_index)
         sd = self.sh_degree_now()
         bg = None
         if c.random_background:

@@ -125,3 +125,36 @@ def test_ensure_downscaled_images_and_device_resize_on_load(tmp_path):
     assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "4") == 0     # already complete
     assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "1") == 0
     assert dataset.ensure_downscaled_images(str(tmp_path / "images"), "abc") == 0
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_resolution_schedule_trains_on_box_filtered_targets(u8):
+    """splatfacto's coarse-to-fine schedule: level d renders (W//d, H//d) with K/d against the d x d block mean."""
+    from oracle import gs_oracle as O
+    W, H = 100, 72                                           # 72 // 4 = 18, 100 // 4 = 25; not divisible at d = 8
+    sc = small_scene(n=1200, seed=31, width=W, height=H, n_views=2, fx=95.0).to(DEV)
+    imgs_u8 = (torch.rand(2, H, W, 3, generator=torch.Generator().manual_seed(2)) * 255).to(torch.uint8).to(DEV)
+    images = imgs_u8 if u8 else imgs_u8.float() / 255.0
+    cfg = trainer.TrainConfig(densify=False, num_downscales=3, resolution_schedule=2, lr_means=0.0, lr_scales=0.0,
+                              lr_quats=0.0, lr_opacities=0.0, lr_sh0=0.0, lr_shN=0.0, sh_degree_interval=1)
+    tr = trainer.Trainer({k: v.clone() for k, v in sc.params.items()}, sc.viewmats, sc.Ks, images, W, H, cfg)
+    seen = []
+    for step in range(8):
+        loss = tr.step(step % 2, want_loss=True)
+        d = 2 ** max(3 - step // 2, 0)
+        seen.append((tr.W, tr.H))
+        assert (tr.W, tr.H) == (W // d, H // d)
+        K = sc.Ks[step % 2].clone()
+        K[:2] /= d
+        P = sc.params
+        sd = min(step, 3)
+        img, _, _ = ops.rasterization(P["means"], P["quats"], P["scales"].exp(), torch.sigmoid(P["opacities"]),
+                                      torch.cat([P["sh0"], P["shN"]], 1), sc.viewmats[step % 2][None], K[None], W // d,
+                                      H // d, sh_degree=sd)
+        src = imgs_u8[step % 2].cpu().numpy()[: (H // d) * d, : (W // d) * d]
+        gt = torch.from_numpy(PO.area_downscale(src, H // d, W // d, as_float=True))[None]
+        want = float(O.photometric_loss(img.double().cpu(), gt, 0.2))
+        assert abs(loss - want) < 2e-5 * max(1.0, abs(want))
+    assert seen[0] == (12, 9) and seen[-1] == (W, H)
+    r, a = tr.render(sc.viewmats[0], sc.Ks[0])               # rendering is always full resolution
+    assert r.shape == (1, H, W, 3)
