@@ -144,11 +144,37 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     __syncthreads();
     uint32_t base = blockIdx.x * RS_TILE;
     if (base < n) {
+        // 16 CONSECUTIVE keys per thread, one LDS atomic per run of equal digits: on the pass over
+        // the high tile bits a Gaussian's neighbouring tiles share the digit, and 64 lanes adding
+        // to one or two counters serialise
+        uint32_t first = base + threadIdx.x * RS_ITEMS;
+        uint32_t k[RS_ITEMS];
+        if (first + RS_ITEMS <= n) {
+            const uint4* k4 = reinterpret_cast<const uint4*>(keys + first);
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS / 4; i++) {
+                uint4 v = k4[i];
+                k[4 * i] = v.x; k[4 * i + 1] = v.y; k[4 * i + 2] = v.z; k[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; i++) k[i] = first + i < n ? keys[first + i] : 0u;
+        }
+        uint32_t cnt_valid = first >= n ? 0u : (n - first < RS_ITEMS ? n - first : RS_ITEMS);
+        uint32_t run_d = (k[0] >> shift) & mask, run = 0;
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; i++) {
-            uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-            if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+            uint32_t d = (k[i] >> shift) & mask;
+            if ((uint32_t)i < cnt_valid) {
+                if (d != run_d) {
+                    atomicAdd(&h[run_d], run);
+                    run_d = d;
+                    run = 0;
+                }
+                run++;
+            }
         }
+        if (run) atomicAdd(&h[run_d], run);
     }
     __syncthreads();
     hist[threadIdx.x * B + blockIdx.x] = h[threadIdx.x];
@@ -170,14 +196,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int i = 0; i < 4; i++) cnt[i][threadIdx.x] = 0;
     __syncthreads();
     uint32_t wbase = block_base + w * RS_WAVE_TILE;
-    uint32_t key[RS_ITEMS], loc[RS_ITEMS];
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], loc[RS_ITEMS];
     unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // Every global read of the block is issued here, before any of it is needed: keys, values and
+    // the block's row of the scanned histogram used to be three dependent round trips (keys ->
+    // rank -> histogram -> barrier -> values -> barrier), each several microseconds under load.
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
-        uint32_t k = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        uint32_t d = (k >> shift) & mask;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
+    }
+    const uint32_t my_global = hist_scanned[threadIdx.x * B + blockIdx.x];     // digit = threadIdx.x
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        uint32_t idx = wbase + r * 64 + lane;
+        bool valid = idx < n;
+        uint32_t d = (key[r] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -189,7 +225,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t npeers = __popcll(peers);
         uint32_t pre = valid ? cnt[w][d] : 0;
         if (valid && rank == npeers - 1) cnt[w][d] = pre + npeers;
-        key[r] = k;
         loc[r] = pre + rank;
     }
     __syncthreads();
@@ -202,7 +237,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
         uint32_t lstart = block_excl_scan_u32(c0 + c1 + c2 + c3, &tot, lds4);   // first local slot of digit d
         cnt[0][d] = lstart; cnt[1][d] = lstart + c0; cnt[2][d] = lstart + c0 + c1; cnt[3][d] = lstart + c0 + c1 + c2;
-        delta[d] = hist_scanned[d * B + blockIdx.x] - lstart;                    // global = local + delta[digit]
+        delta[d] = my_global - lstart;                                           // global = local + delta[digit]
     }
     __syncthreads();
 #pragma unroll
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
             uint32_t d = (key[r] >> shift) & mask;
             uint32_t slot = cnt[w][d] + loc[r];
             skey[slot] = key[r];
-            sval[slot] = vals_in[idx];
+            sval[slot] = val[r];
         }
     }
     __syncthreads();
@@ -294,13 +329,22 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
     if (block_base >= n) return;                      // later tiles are empty too: nobody waits on this one
     int w = threadIdx.x >> 6, lane = lane_id();
     uint32_t wbase = block_base + w * RS_WAVE_TILE;
-    uint32_t key[RS_ITEMS], loc[RS_ITEMS];
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], loc[RS_ITEMS];
     unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // all global reads up front: the values travel while the ranking and the look-back run
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
-        uint32_t k = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
+    }
+    const uint32_t my_ghist = ghist_pass[threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        uint32_t idx = wbase + r * 64 + lane;
+        bool valid = idx < n;
+        uint32_t k = key[r];
         uint32_t d = (k >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -313,7 +357,6 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         uint32_t npeers = __popcll(peers);
         uint32_t pre = valid ? cnt[w][d] : 0;
         if (valid && rank == npeers - 1) cnt[w][d] = pre + npeers;
-        key[r] = k;
         loc[r] = pre + rank;
     }
     __syncthreads();
@@ -346,7 +389,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         }
         // digit base = exclusive scan of the global histogram; local start = exclusive scan of this tile's counts
         uint32_t t2;
-        uint32_t dbase = block_excl_scan_u32(ghist_pass[d], &t2, lds4);
+        uint32_t dbase = block_excl_scan_u32(my_ghist, &t2, lds4);
         uint32_t lstart = block_excl_scan_u32(mine, &tot, lds4);
         cnt[0][d] = lstart; cnt[1][d] = lstart + c0; cnt[2][d] = lstart + c0 + c1; cnt[3][d] = lstart + c0 + c1 + c2;
         delta[d] = dbase + excl - lstart;                                 // global = local slot + delta[digit]
@@ -359,7 +402,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
             uint32_t d = (key[r] >> shift) & mask;
             uint32_t slot = cnt[w][d] + loc[r];
             skey[slot] = key[r];
-            sval[slot] = vals_in[idx];
+            sval[slot] = val[r];
         }
     }
     __syncthreads();

@@ -499,7 +499,24 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     if (live) rad = *reinterpret_cast<const int2*>(radii + 2 * (long long)n);
     const bool vis = live && rad.x > 0 && rad.y > 0;
     const bool need_coef = sh_degree >= 1 && __ballot(vis) != 0ull;
-    if (need_coef) slice_load(slice, shN + 45 * (long long)n0, count, lane);
+    // FUSE: the lane that stages float4 number i4 of the slice is also the lane that applies Adam to
+    // it at the end, so the coefficients stay in 48 registers instead of being read from HBM twice
+    // (the kernel sits at 3 waves per SIMD because of its LDS, which leaves 168 VGPRs).
+    float4 keep[(SH_WAVE_F4 + 63) / 64];
+    if (need_coef) {
+        if (FUSE) {
+            const float4* s4 = reinterpret_cast<const float4*>(shN + 45 * (long long)n0);
+            float4* l4 = reinterpret_cast<float4*>(slice);
+#pragma unroll
+            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
+                int i4 = lane + 64 * j;
+                if (i4 < (count >> 2)) { keep[j] = s4[i4]; l4[i4] = keep[j]; }
+            }
+            if (lane < (count & 3)) slice[(count & ~3) + lane] = shN[45 * (long long)n0 + (count & ~3) + lane];
+        } else {
+            slice_load(slice, shN + 45 * (long long)n0, count, lane);
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // same-wave LDS hand-off: ordering only
 
     GeoGrad G;
@@ -640,7 +657,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
         for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
             int i4 = lane + 64 * j;
             if (i4 < n4) {
-                float4 g = g4[i4], pp = p4[i4], mm = m4[i4], vv = v4[i4];
+                float4 g = g4[i4], pp = need_coef ? keep[j] : p4[i4], mm = m4[i4], vv = v4[i4];
                 mi_adam1(pp.x, g.x, mm.x, vv.x, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
                 mi_adam1(pp.y, g.y, mm.y, vv.y, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
                 mi_adam1(pp.z, g.z, mm.z, vv.z, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
