@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
+    ap.add_argument("--two-phase-binning", action="store_true",
+                    help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
 
 
@@ -111,7 +113,7 @@ def build_workload(args, rank, dev):
         # fixed-N workload: statistics are accumulated every step (their cost is in the step),
         # the every-100-steps refine pass is timed separately below
         refine_start_iter=10 ** 9,
-        max_isect=None if args.sync_isect else 0)
+        max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning)
     tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
     tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
     if not args.sync_isect:

@@ -128,6 +128,17 @@ int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int
                     int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
                     int64_t* isect_ids_opt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Both phases in one call for callers that bring a capacity (no count to read back): depth sort,
+ * then counting and emission fused in one chained pass over the depth-sorted splats (no separate
+ * tile_count / scan, the row tables are built once).  Outputs as above; n_isect_dev receives the
+ * (uncapped) number of intersections, tiles_per_gauss_opt[C*N] is nullable. */
+int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float* splats, int tile_size,
+                     int tile_width, int tile_height, int height, int tight,
+                     int32_t* n_isect_dev, long long max_isect,
+                     int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
+                     int64_t* isect_ids_opt, int32_t* tiles_per_gauss_opt,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* building blocks of the above, exported for reuse and for tests */
 size_t mi3dgs_sort_workspace_bytes(long long n);
 int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits, void* workspace,

@@ -674,26 +674,103 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(uint32_t n, const uint3
 // consecutive slots (coalesced 1-KiB stores) and finds each slot's Gaussian by binary search
 // over the 256 exclusive offsets held in LDS.  (Thread-per-Gaussian emission measured 3.5x
 // HBM write amplification.)
-template <bool TIGHT>
+// sort input of the fused path (mi3dgs_bin_tiles): depth key + identity, culled splats last
+__global__ __launch_bounds__(256) void depth_keys_kernel(uint32_t CN, const int32_t* __restrict__ radii,
+                                                         const float* __restrict__ splats,
+                                                         uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= CN) return;
+    int2 r = *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
+    uint32_t key = 0xFFFFFFFFu;
+    if (r.x > 0 && r.y > 0) key = __float_as_uint(splats[(size_t)idx * SPLAT_STRIDE + SP_DEPTH]);
+    depth_keys[idx] = key;
+    ids[idx] = idx;
+}
+
+// ---- single-value decoupled look-back (chained scan) for the fused count+emit kernel.  One
+// 64-bit word per block {flag:2 (bits 32..33) | value:32}: flag 1 = the block's own total,
+// 2 = inclusive prefix; zero (the memset state) = not there yet.  Block ids are handed out by an
+// atomic counter, so every predecessor is already running and each wait ends.  Wave 0 calls this
+// with all 64 lanes and inspects 64 predecessors per step.  Agent-scope atomics: the per-XCD L2s
+// are not coherent with one another.
+__device__ __forceinline__ unsigned long long chain_pack(uint32_t flag, uint32_t v) {
+    return ((unsigned long long)flag << 32) | v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t chain_lookback(unsigned long long* status, uint32_t blk, uint32_t total, int lane,
+                                                   uint32_t* err) {
+    if (lane == 0)
+        __hip_atomic_store(status + blk, chain_pack(blk == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    if (blk > 0) {
+        int p = (int)blk - 1;
+        while (true) {
+            int idx = p - lane;
+            unsigned long long w = chain_pack(2u, 0u);              // before block 0: prefix 0
+            if (idx >= 0) {
+                unsigned spins = 0;
+                while (true) {
+                    w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((w >> 32) & 3ull) != 0ull) break;
+                    if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 2u); w = chain_pack(2u, 0u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            uint32_t val = (uint32_t)w;
+            unsigned long long pm = __ballot(((w >> 32) & 3ull) == 2ull);
+            if (pm) {
+                int f = __ffsll((long long)pm) - 1;                  // nearest predecessor holding a prefix
+                excl += wave_sum_u32(lane <= f ? val : 0u);
+                break;
+            }
+            excl += wave_sum_u32(val);
+            p -= 64;
+        }
+        if (lane == 0)
+            __hip_atomic_store(status + blk, chain_pack(2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return excl;
+}
+
+// CHAINED = false: offsets come from `cum` (mi3dgs_bin_count ran tile_count + gather + scan before).
+// CHAINED = true : count and emit in ONE pass over the depth-sorted splats: the block builds its row
+// table once, chains its total through `status`, and emits; tile_count, the gather and the
+// three-kernel scan (and the second row-table build) disappear.  The last block leaves the
+// total in *n_isect_out.
+template <bool TIGHT, bool CHAINED>
 __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N, const uint32_t* __restrict__ sorted_ids,
                                                         const uint32_t* __restrict__ cum,
                                                         const int32_t* __restrict__ radii,
                                                         const float* __restrict__ splats, int tile_size, int tw, int th,
                                                         int H, uint32_t cap, uint32_t* __restrict__ tile_keys,
-                                                        uint32_t* __restrict__ flat_ids) {
+                                                        uint32_t* __restrict__ flat_ids,
+                                                        unsigned long long* status, uint32_t* chain_counter,
+                                                        uint32_t* chain_err, uint32_t* __restrict__ n_isect_out,
+                                                        uint32_t* __restrict__ tiles_out) {
     __shared__ uint32_t s_cum[257];
     __shared__ uint32_t s_id[256], s_key0[256];
     __shared__ int s_w[256];
     __shared__ uint8_t s_slow[256];
     __shared__ SpanGeom s_geo[TIGHT ? 256 : 1];
     __shared__ RowTable T[1];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_blk, s_base, s_scan4[4];
+    uint32_t blk = blockIdx.x;
+    if (CHAINED) {
+        if (threadIdx.x == 0) s_blk = atomicAdd(chain_counter, 1u);
+        __syncthreads();
+        blk = s_blk;
+    }
+    uint32_t i = blk * blockDim.x + threadIdx.x;
     uint32_t my_cum = 0, my_n = 0, idx = 0, key0 = 0;
     int w = 1;
     bool vis = false;
     if (i < CN) {
         idx = sorted_ids[i];
-        my_cum = cum[i];
+        if (!CHAINED) my_cum = cum[i];
         int2 r = *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
         if (r.x > 0 && r.y > 0) {
             vis = true;
@@ -716,12 +793,26 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         my_n = build_row_table(T[0], s_geo, vis, tile_size, H, slow);   // same arithmetic as tile_count_kernel<true>
         s_slow[threadIdx.x] = slow ? 1 : 0;
     }
+    if (CHAINED) {
+        uint32_t total;
+        uint32_t local = block_excl_scan_u32(my_n, &total, s_scan4);
+        if (threadIdx.x < 64) {
+            uint32_t excl = chain_lookback(status, blk, total, (int)threadIdx.x, chain_err);
+            if (threadIdx.x == 0) {
+                s_base = excl;
+                if (blk == gridDim.x - 1) *n_isect_out = excl + total;
+            }
+        }
+        __syncthreads();
+        my_cum = s_base + local;
+        if (tiles_out && i < CN) tiles_out[idx] = my_n;
+    }
     s_cum[threadIdx.x] = my_cum;
     s_id[threadIdx.x] = idx;
     s_key0[threadIdx.x] = key0;
     s_w[threadIdx.x] = w;
     // the last live thread of the block publishes the end of the block's range
-    uint32_t last = min(CN - blockIdx.x * blockDim.x, blockDim.x) - 1;
+    uint32_t last = min(CN - blk * blockDim.x, blockDim.x) - 1;
     if (threadIdx.x == last) s_cum[256] = my_cum + my_n;
     __syncthreads();
     uint32_t begin = s_cum[0], end = s_cum[256];
@@ -878,6 +969,29 @@ extern "C" int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float*
 
 // Phase 2: emit (tile key, flat id) in depth order, stable sort by tile key, tile offsets.
 // flatten_ids / tile_keys have max_isect entries; the live count is n_isect_dev[0] (device).
+// stable sort of the emitted (tile key, splat) pairs on the tile bits, then the per-tile offsets
+static int bin_sort_and_offsets(const BinWs& ws, uint32_t* tk, uint32_t* fi, const int32_t* n_isect_dev, uint32_t cap,
+                                uint32_t n_tiles_total, const float* splats, int32_t* isect_offsets,
+                                int64_t* isect_ids_opt, hipStream_t st) {
+    int nbits = 1;
+    while ((1u << nbits) < n_tiles_total) nbits++;
+    int in_b = 0;
+    int rc = radix_sort_pairs(tk, fi, ws.tk_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st, "isect");
+    if (rc) return rc;
+    if (in_b) {
+        MI_HIP(hipMemcpyAsync(tk, ws.tk_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
+        MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
+    }
+    uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
+    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(g, 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
+                       cap, n_tiles_total, isect_offsets);
+    if (isect_ids_opt)
+        MI_LAUNCH("isect_ids", isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
+                           (const uint32_t*)n_isect_dev, cap, splats, isect_ids_opt);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int tile_size, int tile_width,
                                int tile_height, int height, int tight, const int32_t* n_isect_dev, long long max_isect,
                                int32_t* flatten_ids,
@@ -897,29 +1011,68 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     if (tight)
-        MI_LAUNCH("tile_emit", tile_emit_kernel<true>, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
-                  ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi);
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
+                  ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
+                  nullptr, nullptr, nullptr);
     else
-        MI_LAUNCH("tile_emit", tile_emit_kernel<false>, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
-                  ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi);
-    int nbits = 1;
-    while ((1u << nbits) < n_tiles_total) nbits++;
-    int in_b = 0;
-    int rc = radix_sort_pairs(tk, fi, ws.tk_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st, "isect");
-    if (rc) return rc;
-    if (in_b) {
-        MI_HIP(hipMemcpyAsync(tk, ws.tk_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
-        MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
-    }
-    uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
-    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(g, 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
-                       cap, n_tiles_total, isect_offsets);
-    if (isect_ids_opt)
-        MI_LAUNCH("isect_ids", isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
-                           (const uint32_t*)n_isect_dev, cap, splats, isect_ids_opt);
-    MI_LAUNCH_CHECK();
-    return 0;
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
+                  ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
+                  nullptr, nullptr, nullptr);
+    return bin_sort_and_offsets(ws, tk, fi, n_isect_dev, cap, n_tiles_total, splats, isect_offsets, isect_ids_opt, st);
 }
+
+// One-call binning for callers that bring a capacity (the training step): depth sort, then count
+// and emit fused in one chained pass.  Same outputs as mi3dgs_bin_count + mi3dgs_bin_emit.
+extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float* splats, int tile_size, int tile_width,
+                                int tile_height, int height, int tight, int32_t* n_isect_dev, long long max_isect,
+                                int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
+                                int64_t* isect_ids_opt, int32_t* tiles_per_gauss_opt, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    long long CNl = (long long)C * N;
+    MI_REQUIRE(CNl < (1ll << 31), "bin_tiles: C*N must be < 2^31");
+    MI_REQUIRE((long long)C * tile_width * tile_height < (1ll << 31), "bin_tiles: too many tiles");
+    MI_REQUIRE(max_isect >= 0 && max_isect < (1ll << 31), "bin_tiles: bad max_isect");
+    uint32_t CN = (uint32_t)CNl;
+    uint32_t cap = (uint32_t)max_isect;
+    uint32_t n_tiles_total = (uint32_t)(C * tile_width * tile_height);
+    hipStream_t st = (hipStream_t)stream;
+    MI_REQUIRE(n_isect_dev && isect_offsets, "bin_tiles: null output");
+    if (CN == 0 || cap == 0) {
+        MI_HIP(hipMemsetAsync(n_isect_dev, 0, 4, st));
+        MI_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, st));
+        if (tiles_per_gauss_opt && CN) MI_HIP(hipMemsetAsync(tiles_per_gauss_opt, 0, (size_t)CN * 4, st));
+        return 0;
+    }
+    BinWs ws;
+    size_t need = bin_ws_layout(CN, cap, (uint32_t*)workspace, &ws);
+    MI_REQUIRE(workspace && workspace_bytes >= need, "bin_tiles: workspace too small");
+    MI_REQUIRE(flatten_ids && tile_keys, "bin_tiles: null output");
+    MI_LAUNCH("depth_keys", depth_keys_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, ws.dkeys_a,
+              ws.ids_a);
+    int in_b = 0;
+    int rc = radix_sort_pairs(ws.dkeys_a, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth");
+    if (rc) return rc;
+    const uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
+    // chain state lives in the (unused here) `cum` array: status[nblocks] u64 | counter | err
+    uint32_t nblocks = (uint32_t)mi_div_up(CN, 256);
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(ws.cum);
+    uint32_t* counter = ws.cum + 2 * (size_t)nblocks;
+    uint32_t* err = counter + 1;
+    MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 2) * sizeof(uint32_t), st));
+    uint32_t* tk = (uint32_t*)tile_keys;
+    uint32_t* fi = (uint32_t*)flatten_ids;
+    if (tight)
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
+                  nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    else
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
+                  nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    MI_LAUNCH_CHECK();
+    return bin_sort_and_offsets(ws, tk, fi, n_isect_dev, cap, n_tiles_total, splats, isect_offsets, isect_ids_opt, st);
+}
+
 
 // Standalone entry points (exported for tests and for reuse by densify compaction).
 extern "C" size_t mi3dgs_sort_workspace_bytes(long long n) {

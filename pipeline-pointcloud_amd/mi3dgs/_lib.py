@@ -39,6 +39,7 @@ _SIGNATURES = {
     "mi3dgs_bin_workspace_bytes": (_sz, [_i, _i, _ll]),
     "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
     "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),
+    "mi3dgs_bin_tiles": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _f, _sz, _f]),
     "mi3dgs_sort_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_debug_set_sort_mode": (_i, [_i]),

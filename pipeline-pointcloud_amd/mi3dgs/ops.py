@@ -143,7 +143,8 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
-              want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False):
+              want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False,
+              fused: bool = True):
     """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops
     the (tile, splat) pairs the ellipse sigma <= ln(255 o) cannot reach (identical renders and
     gradients, fewer intersections).  With max_isect=None the intersection count is read back (one host
@@ -160,6 +161,22 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     ws_bytes = _lib.lib().mi3dgs_bin_workspace_bytes(Cn, N, cap)
     ws = workspace(ws_bytes, dev)
     st = _stream(dev)
+    if cap_known and fused:
+        # capacity given: one call, counting and emission fused in a chained pass
+        flatten_ids = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        tile_keys = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(Cn, th, tw, dtype=torch.int32, device=dev)
+        isect_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
+        _lib.call("mi3dgs_bin_tiles", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+                  _p(n_isect), cap, _p(flatten_ids), _p(tile_keys), _p(offsets), _p(isect_ids), _p(tpg), _p(ws),
+                  ws.numel(), st)
+        out = dict(n_isect=n_isect, flatten_ids=flatten_ids, tile_keys=tile_keys, isect_offsets=offsets,
+                   tile_width=tw, tile_height=th, max_isect=cap)
+        if want_isect_ids:
+            out["isect_ids"] = isect_ids
+        if want_tiles_per_gauss:
+            out["tiles_per_gauss"] = tpg
+        return out
     _lib.call("mi3dgs_bin_count", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
               _p(tpg), _p(n_isect), _p(ws), ws.numel(), cap, st)
     if not cap_known:

@@ -73,6 +73,8 @@ class TrainConfig:
     max_isect: Optional[int] = None
     # exact ellipse-tile culling at binning time (identical renders/gradients, fewer intersections)
     tight_tiles: bool = True
+    # capacity mode only: count and emit fused in one chained pass (mi3dgs_bin_tiles)
+    fused_binning: bool = True
     # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
     # gradients for its all-reduce and switches this off)
     fuse_adam: bool = True
@@ -212,7 +214,8 @@ class Trainer:
         ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats)
-        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles)
+        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles,
+                                fused=self.cfg.fused_binning)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids

@@ -123,6 +123,36 @@ def test_binning_bit_exact_vs_oracle(dev, big, n_views):
     assert torch.equal(b2["isect_offsets"].cpu(), offs)
 
 
+@pytest.mark.parametrize("tight", [False, True])
+@pytest.mark.parametrize("n,n_views,big", [(700, 1, False), (3000, 2, True), (5, 1, True), (70000, 1, False)])
+def test_fused_binning_equals_the_two_phase_path(dev, tight, n, n_views, big):
+    """mi3dgs_bin_tiles (depth sort + chained count/emit) against mi3dgs_bin_count + mi3dgs_bin_emit, bit for bit."""
+    ops = _ops()
+    sc = small_scene(n=n, seed=17, big=big, n_views=n_views, width=200 if n > 10000 else 80, height=120 if n > 10000 else 56)
+    g = sc.to(dev)
+    radii, splats = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                                    g.viewmats, g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"],
+                                    sh_degree=3, flags=3)
+    ref = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, want_isect_ids=True, want_tiles_per_gauss=True, tight=tight)
+    I = int(ref["n_isect"].item())
+    assert I > 0
+    for cap in (I + 777, I, max(I // 2, 1)):                 # roomy, exact, overflowing capacity
+        for fused in (True, False):
+            b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=cap, want_isect_ids=True,
+                              want_tiles_per_gauss=True, tight=tight, fused=fused)
+            assert int(b["n_isect"].item()) == I
+            assert torch.equal(b["tiles_per_gauss"], ref["tiles_per_gauss"])
+            if cap >= I:
+                assert torch.equal(b["flatten_ids"][:I], ref["flatten_ids"])
+                assert torch.equal(b["tile_keys"][:I], ref["tile_keys"])
+                assert torch.equal(b["isect_ids"][:I], ref["isect_ids"])
+                assert torch.equal(b["isect_offsets"], ref["isect_offsets"])
+            else:
+                # overflow: the first `cap` emitted pairs (depth order) are kept, sorted by tile
+                k = b["tile_keys"][:cap]
+                assert bool((k[1:] >= k[:-1]).all())
+
+
 def test_binning_empty_scene(dev):
     ops = _ops()
     sc = small_scene(n=50, seed=6)
@@ -133,6 +163,8 @@ def test_binning_empty_scene(dev):
                                     flags=3)
     assert int((radii > 0).sum()) == 0
     b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16)
+    assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
+    b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=1000)       # fused path
     assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
     bg = torch.rand(2, 3, device=dev)
     r, a, _ = ops.rasterize_fwd(splats, b, sc.width, sc.height, 16, bg)
