@@ -236,6 +236,14 @@ int mi3dgs_knn(long long n, const float* points, int k, float* out_d2, int32_t* 
 int mi3dgs_image_downscale_area(const uint8_t* src, int height, int width, int channels, void* dst,
                                 int out_height, int out_width, int dst_is_f32, void* stream);
 int mi3dgs_image_u8_to_f32(const uint8_t* src, long long n, float* dst, float scale, void* stream);
+/* Lens undistortion to a pinhole image (cv2.undistort as nerfstudio's datamanager applies it before
+ * training, reached through reference main.py:1303-1306): dst(u,v) = bilinear sample of src at
+ * K_src * distort(K_dst^-1 (u,v)), zero outside.  k_src / k_dst / dist are HOST arrays: (fx, fy,
+ * cx, cy) each; model 0 = OpenCV (k1 k2 p1 p2 k3 k4 k5 k6, missing ones zero), 1 = OpenCV fisheye
+ * (k1..k4).  dst u8 (round to nearest) or f32 in [0,1]. */
+int mi3dgs_image_undistort(const uint8_t* src, int height, int width, int channels, void* dst,
+                           int out_height, int out_width, const float* k_src, const float* k_dst,
+                           int model, const float* dist, int n_dist, int dst_is_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,38 @@ def area_downscale(img_u8, out_h, out_w, as_float=False):
     if as_float:
         return r / 255.0
     return np.clip(np.rint(r), 0, 255).astype(np.uint8)
+
+
+def undistort_image(img_u8, k_src, k_dst, dist, out_h, out_w, fisheye=False):
+    """cv2.undistort semantics in float64: output (u, v) <- bilinear sample of the source at
+    K_src * distort(K_dst^-1 (u, v)), zero outside (OpenCV initUndistortRectifyMap + remap
+    INTER_LINEAR / BORDER_CONSTANT, without remap's 1/32-pixel coefficient quantisation).  Returns
+    float64 in [0, 255]."""
+    a = np.asarray(img_u8, dtype=np.float64)
+    H, W = a.shape[:2]
+    d = list(dist) + [0.0] * (8 - len(dist))
+    u, v = np.meshgrid(np.arange(out_w, dtype=np.float64), np.arange(out_h, dtype=np.float64))
+    x, y = (u - k_dst[2]) / k_dst[0], (v - k_dst[3]) / k_dst[1]
+    if not fisheye:
+        r2 = x * x + y * y
+        rad = (1 + r2 * (d[0] + r2 * (d[1] + r2 * d[4]))) / (1 + r2 * (d[5] + r2 * (d[6] + r2 * d[7])))
+        xd = x * rad + 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x)
+        yd = y * rad + d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y
+    else:
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan(r)
+        t2 = th * th
+        thd = th * (1 + t2 * (d[0] + t2 * (d[1] + t2 * (d[2] + t2 * d[3]))))
+        sc = np.where(r > 1e-8, thd / np.maximum(r, 1e-300), 1.0)
+        xd, yd = x * sc, y * sc
+    us, vs = k_src[0] * xd + k_src[2], k_src[1] * yd + k_src[3]
+    x0, y0 = np.floor(us).astype(np.int64), np.floor(vs).astype(np.int64)
+    ax, ay = (us - x0)[..., None], (vs - y0)[..., None]
+    out = np.zeros((out_h, out_w, a.shape[2]))
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = x0 + dx, y0 + dy
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            wgt = (ax if dx else 1 - ax) * (ay if dy else 1 - ay)
+            out += np.where(ok[..., None], wgt * a[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], 0.0)
+    return out

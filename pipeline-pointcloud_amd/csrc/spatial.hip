@@ -454,6 +454,66 @@ __global__ __launch_bounds__(256) void area_down_kernel(const uint8_t* __restric
     }
 }
 
+// Lens undistortion (what nerfstudio's datamanager does with cv2.undistort before training,
+// reached through reference main.py:1303-1306; the multi-GPU branch runs COLMAP's undistorter
+// instead, main.py:1157-1180).  Output pixel (u, v) of the pinhole camera K_dst looks up the source
+// image at distort((u - cx') / fx', (v - cy') / fy') through K_src, bilinear, zero outside (cv2
+// remap INTER_LINEAR / BORDER_CONSTANT; pixel index = coordinate, the caller shifts principal
+// points as it wishes).  model 0: OpenCV rational + tangential (k1 k2 p1 p2 k3 k4 k5 k6; covers
+// COLMAP SIMPLE_RADIAL / RADIAL / OPENCV / FULL_OPENCV), 1: OpenCV fisheye (k1..k4).
+struct UndistortArgs {
+    float fx, fy, cx, cy;          // source (distorted) camera
+    float nfx, nfy, ncx, ncy;      // destination pinhole
+    float d[8];
+    int model;
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void undistort_kernel(const uint8_t* __restrict__ src, int H, int W, int Cn,
+                                                        OutT* __restrict__ dst, int h, int w, UndistortArgs A,
+                                                        float out_scale) {
+    int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (u >= w || v >= h) return;
+    float x = ((float)u - A.ncx) / A.nfx, y = ((float)v - A.ncy) / A.nfy;
+    float xd, yd;
+    if (A.model == 0) {
+        float r2 = x * x + y * y;
+        float num = 1.f + r2 * (A.d[0] + r2 * (A.d[1] + r2 * A.d[4]));
+        float den = 1.f + r2 * (A.d[5] + r2 * (A.d[6] + r2 * A.d[7]));
+        float rad = num / den;
+        xd = x * rad + 2.f * A.d[2] * x * y + A.d[3] * (r2 + 2.f * x * x);
+        yd = y * rad + A.d[2] * (r2 + 2.f * y * y) + 2.f * A.d[3] * x * y;
+    } else {
+        float r = sqrtf(x * x + y * y);
+        float th = atanf(r), t2 = th * th;
+        float thd = th * (1.f + t2 * (A.d[0] + t2 * (A.d[1] + t2 * (A.d[2] + t2 * A.d[3]))));
+        float sc = r > 1e-8f ? thd / r : 1.f;
+        xd = x * sc; yd = y * sc;
+    }
+    float us = A.fx * xd + A.cx, vs = A.fy * yd + A.cy;
+    float fu = floorf(us), fv = floorf(vs);
+    int x0 = (int)fu, y0 = (int)fv;
+    float ax = us - fu, ay = vs - fv;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (us > -1.f && vs > -1.f && us < (float)W && vs < (float)H) {
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                int xx = x0 + dx, yy = y0 + dy;
+                float wgt = (dx ? ax : 1.f - ax) * (dy ? ay : 1.f - ay);
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    const uint8_t* p = src + ((size_t)yy * W + xx) * Cn;
+                    for (int ch = 0; ch < Cn; ch++) acc[ch] += wgt * (float)p[ch];
+                }
+            }
+    }
+    for (int ch = 0; ch < Cn; ch++) {
+        if constexpr (sizeof(OutT) == 1) dst[((size_t)v * w + u) * Cn + ch] = (OutT)fminf(fmaxf(rintf(acc[ch]), 0.f), 255.f);
+        else dst[((size_t)v * w + u) * Cn + ch] = (OutT)(acc[ch] * out_scale);
+    }
+}
+
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ src, size_t n4, size_t n,
                                                         float* __restrict__ dst, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,6 +611,33 @@ extern "C" int mi3dgs_image_u8_to_f32(const uint8_t* src, long long n, float* ds
     size_t threads = n4 > 0 ? n4 : 1;
     MI_LAUNCH("u8_to_f32", u8_to_f32_kernel, dim3(mi_div_up((long long)threads, 256)), dim3(256), 0,
               (hipStream_t)stream, src, n4, (size_t)n, dst, scale);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_image_undistort(const uint8_t* src, int height, int width, int channels, void* dst, int out_height,
+                                      int out_width, const float* k_src, const float* k_dst, int model,
+                                      const float* dist, int n_dist, int dst_is_f32, void* stream) {
+    MI_REQUIRE(src && dst && k_src && k_dst, "image_undistort: null pointer");
+    MI_REQUIRE(channels >= 1 && channels <= 4, "image_undistort: channels must be in [1,4]");
+    MI_REQUIRE(height >= 1 && width >= 1 && out_height >= 1 && out_width >= 1 && out_height <= 65535,
+               "image_undistort: bad image size");
+    MI_REQUIRE(model == 0 || model == 1, "image_undistort: model must be 0 (OpenCV) or 1 (OpenCV fisheye)");
+    MI_REQUIRE(n_dist >= 0 && n_dist <= (model == 0 ? 8 : 4) && (n_dist == 0 || dist), "image_undistort: bad coefficients");
+    MI_REQUIRE(k_src[0] != 0.f && k_src[1] != 0.f && k_dst[0] != 0.f && k_dst[1] != 0.f, "image_undistort: zero focal length");
+    UndistortArgs A;
+    A.fx = k_src[0]; A.fy = k_src[1]; A.cx = k_src[2]; A.cy = k_src[3];      // HOST arrays: 4 floats each
+    A.nfx = k_dst[0]; A.nfy = k_dst[1]; A.ncx = k_dst[2]; A.ncy = k_dst[3];
+    for (int i = 0; i < 8; i++) A.d[i] = i < n_dist ? dist[i] : 0.f;
+    A.model = model;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(mi_div_up(out_width, 256), out_height);
+    if (dst_is_f32)
+        MI_LAUNCH("undistort", undistort_kernel<float>, grid, dim3(256), 0, st, src, height, width, channels, (float*)dst,
+                  out_height, out_width, A, 1.0f / 255.0f);
+    else
+        MI_LAUNCH("undistort", undistort_kernel<uint8_t>, grid, dim3(256), 0, st, src, height, width, channels,
+                  (uint8_t*)dst, out_height, out_width, A, 1.0f);
     MI_LAUNCH_CHECK();
     return 0;
 }

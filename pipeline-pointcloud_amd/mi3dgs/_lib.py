@@ -63,6 +63,8 @@ _SIGNATURES = {
     "mi3dgs_knn": (_i, [_ll, _f, _i, _f, _f, _f, _sz, _f]),
     "mi3dgs_image_downscale_area": (_i, [_f, _i, _i, _i, _f, _i, _i, _i, _f]),
     "mi3dgs_image_u8_to_f32": (_i, [_f, _ll, _f, _fl, _f]),
+    "mi3dgs_image_undistort": (_i, [_f, _i, _i, _i, _f, _i, _i, C.POINTER(_fl), C.POINTER(_fl), _i, C.POINTER(_fl), _i,
+                                    _i, _f]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

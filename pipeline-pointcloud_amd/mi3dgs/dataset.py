@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import io_colmap
+from . import undistort as ud
 
 SH_C0 = 0.28209479177387814
 IMAGE_EXTS = (".jpg", ".jpeg", ".png", ".JPG", ".JPEG", ".PNG")
@@ -44,6 +45,7 @@ class Dataset:
     scale: float
     train_idx: List[int] = field(default_factory=list)
     eval_idx: List[int] = field(default_factory=list)
+    undistort: List[Optional[object]] = field(default_factory=list)   # per image: undistort.Plan or None
 
     def load_images(self, idx: List[int], device, as_u8: bool = False) -> torch.Tensor:
         """[len(idx),H,W,3] on `device`: float32 in [0,1], or uint8 (`as_u8`, the device image
@@ -58,6 +60,16 @@ class Dataset:
         for j, i in enumerate(idx):
             im = Image.open(self.image_paths[i]).convert("RGB")
             a = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).to(device)
+            plan = self.undistort[i] if self.undistort else None
+            if plan is not None:
+                # (area-average to the size the intrinsics were scaled to, then) resample through the lens model
+                if im.size != plan.src_size:
+                    if im.size[0] < plan.src_size[0] or im.size[1] < plan.src_size[1]:
+                        raise ValueError(f"{self.image_paths[i]}: {im.size} is smaller than the camera's {plan.src_size}")
+                    a = ops.image_downscale_area(a, plan.src_size[1], plan.src_size[0])
+                out[j] = ops.image_undistort(a, plan.k_src, plan.k_dst, plan.dist, self.height, self.width,
+                                             fisheye=plan.fisheye, as_float=not as_u8)
+                continue
             if im.size != (self.width, self.height):
                 if im.size[0] < self.width or im.size[1] < self.height:
                     raise ValueError(f"{self.image_paths[i]}: {im.size} is smaller than the camera's "
@@ -74,7 +86,7 @@ class Dataset:
 
 
 def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: int = 8,
-                        normalize: bool = True) -> Dataset:
+                        normalize: bool = True, undistort: bool = True) -> Dataset:
     sparse = io_colmap.find_sparse_dir(data_dir)
     cams = io_colmap.read_cameras(os.path.join(sparse, "cameras.bin"))
     imgs = io_colmap.read_images(os.path.join(sparse, "images.bin"))
@@ -101,19 +113,32 @@ def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: in
     vm = np.tile(np.eye(4), (len(items), 1, 1))
     vm[:, :3, :3] = R
     vm[:, :3, 3] = t_n
-    Ks, dist_warn = [], False
+    Ks, dist_warn, plans, plan_of = [], False, [], {}
     cam0 = cams[items[0].camera_id]
     W, H = max(1, int(cam0.width / k)), max(1, int(cam0.height / k))       # reference: max(1, int(w / k)), main.py:452
     for im in items:
         c = cams[im.camera_id]
         fx, fy, cx, cy = c.pinhole()
         sx, sy = W / c.width, H / c.height
-        Ks.append([[fx * sx, 0, cx * sx], [0, fy * sy, cy * sy], [0, 0, 1]])
-        if np.abs(c.distortion()).max(initial=0.0) > 1e-6:
+        Kc = (fx * sx, fy * sy, cx * sx, cy * sy)
+        if undistort and im.camera_id not in plan_of:
+            plan_of[im.camera_id] = ud.make_plan(c.model, c.distortion(), Kc, (W, H))
+        plan = plan_of.get(im.camera_id) if undistort else None
+        if plan is not None:
+            Kc = plan.K_out
+        elif np.abs(c.distortion()).max(initial=0.0) > 1e-6:
             dist_warn = True
+        plans.append(plan)
+        Ks.append([[Kc[0], 0, Kc[2]], [0, Kc[1], Kc[3]], [0, 0, 1]])
     if dist_warn:
-        print("[mi3dgs] note: lens distortion parameters present; images are treated as pinhole "
-              "(the reference's multi-GPU branch undistorts first, main.py:1157-1180)")
+        print("[mi3dgs] note: lens distortion parameters present; images are treated as pinhole (undistort=False)")
+    out_sizes = {p.out_size if p is not None else (W, H) for p in plans}
+    if len(out_sizes) != 1:
+        raise ValueError(f"cameras undistort to different image sizes {sorted(out_sizes)}; one size per dataset is supported")
+    src_W, src_H = W, H
+    W, H = out_sizes.pop()
+    if any(p is not None for p in plans):
+        print(f"[mi3dgs] undistorting on the GPU: {src_W}x{src_H} -> {W}x{H} pinhole images")
     V = len(items)
     eval_idx = [i for i in range(V) if test_every > 0 and i % test_every == 0]
     train_idx = [i for i in range(V) if i not in set(eval_idx)] or list(range(V))
@@ -121,7 +146,7 @@ def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: in
     return Dataset(torch.from_numpy(vm).float(), torch.tensor(Ks, dtype=torch.float32),
                    [os.path.join(img_dir, im.name) for im in items], [im.name for im in items], W, H,
                    torch.from_numpy(pts).float(), torch.from_numpy(rgb.copy()), torch.from_numpy(center).float(),
-                   float(scale), train_idx, eval_idx)
+                   float(scale), train_idx, eval_idx, plans)
 
 
 def knn_mean_sq_dist(points: torch.Tensor, k: int = 3) -> torch.Tensor:

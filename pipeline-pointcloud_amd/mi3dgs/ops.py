@@ -335,6 +335,22 @@ def image_downscale_area(img_u8: torch.Tensor, out_h: int, out_w: int, as_float:
     return out
 
 
+def image_undistort(img_u8: torch.Tensor, k_src, k_dst, dist, out_h: int, out_w: int, fisheye: bool = False,
+                    as_float: bool = False) -> torch.Tensor:
+    """Pinhole re-sampling of a distorted [H,W,Ch] uint8 image on the GPU (cv2.undistort semantics):
+    k_src / k_dst = (fx, fy, cx, cy), dist = OpenCV order (k1 k2 p1 p2 k3 k4 k5 k6) or fisheye k1..k4."""
+    import ctypes as C
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or not img_u8.is_cuda or not img_u8.is_contiguous():
+        raise ValueError("image_undistort: expected a contiguous [H,W,Ch] uint8 tensor on the GPU")
+    H, W, Ch = img_u8.shape
+    out = torch.empty(out_h, out_w, Ch, dtype=torch.float32 if as_float else torch.uint8, device=img_u8.device)
+    d = [float(x) for x in dist]
+    ks, kd, dd = (C.c_float * 4)(*[float(x) for x in k_src]), (C.c_float * 4)(*[float(x) for x in k_dst]), (C.c_float * max(len(d), 1))(*d)
+    _lib.call("mi3dgs_image_undistort", _p(img_u8), H, W, Ch, _p(out), int(out_h), int(out_w), ks, kd, int(bool(fisheye)), dd,
+              len(d), int(as_float), _stream(img_u8.device))
+    return out
+
+
 def image_u8_to_f32(img_u8: torch.Tensor, out: Optional[torch.Tensor] = None, scale: float = 1.0 / 255.0):
     """uint8 image (any shape, GPU) -> float32 * scale: the device image cache keeps u8, a step reads f32."""
     if img_u8.dtype != torch.uint8 or not img_u8.is_cuda or not img_u8.is_contiguous():

@@ -158,3 +158,65 @@ def test_resolution_schedule_trains_on_box_filtered_targets(u8):
     assert seen[0] == (12, 9) and seen[-1] == (W, H)
     r, a = tr.render(sc.viewmats[0], sc.Ks[0])               # rendering is always full resolution
     assert r.shape == (1, H, W, 3)
+
+
+UD_CASES = [("OPENCV", [0.09, -0.03, 0.0012, -0.0008], (290.0, 305.0, 163.0, 98.0)),
+            ("FULL_OPENCV", [-0.1, 0.02, 0.0005, 0.0003, 0.001, 0.01, 0.002, 0.0], (300.0, 300.0, 160.0, 100.0)),
+            ("SIMPLE_RADIAL", [-0.12], (280.0, 280.0, 158.0, 103.0)),
+            ("OPENCV_FISHEYE", [0.04, -0.008, 0.001, 0.0], (150.0, 148.0, 161.0, 99.0))]
+
+
+@pytest.mark.parametrize("model,tail,K", UD_CASES)
+@pytest.mark.parametrize("ch", [3, 1])
+def test_undistort_kernel_equals_oracle(model, tail, K, ch):
+    from mi3dgs import undistort as ud
+    w, h = 320, 200
+    p = ud.make_plan(model, tail, K, (w, h))
+    img = np.random.default_rng(len(tail) + ch).integers(0, 256, size=(h, w, ch), dtype=np.uint8)
+    want = PO.undistort_image(img, p.k_src, p.k_dst, p.dist, p.out_size[1], p.out_size[0], p.fisheye)
+    t = torch.from_numpy(img).to(DEV)
+    got_f = ops.image_undistort(t, p.k_src, p.k_dst, p.dist, p.out_size[1], p.out_size[0], fisheye=p.fisheye, as_float=True)
+    got_u = ops.image_undistort(t, p.k_src, p.k_dst, p.dist, p.out_size[1], p.out_size[0], fisheye=p.fisheye)
+    assert got_f.shape == (p.out_size[1], p.out_size[0], ch)
+    # float32 coordinates on a noise image: a 1e-4 px coordinate error times a 255-level step
+    err = np.abs(got_f.cpu().numpy().astype(np.float64) * 255.0 - want)
+    assert err.max() < 0.25 and err.mean() < 0.01
+    assert np.abs(got_u.cpu().numpy().astype(np.float64) - want).max() < 0.76
+    # zero outside the source: a camera looking far past the image border
+    far = ops.image_undistort(t, p.k_src, (p.k_dst[0], p.k_dst[1], p.k_dst[2] - 5000.0, p.k_dst[3]), p.dist, 8, 8,
+                              fisheye=p.fisheye)
+    assert int(far.max()) == 0
+
+
+def test_dataset_undistorts_on_load(tmp_path):
+    """COLMAP OPENCV camera on disk -> pinhole targets: sizes, intrinsics and pixels follow the plan."""
+    from PIL import Image
+    from mi3dgs import io_colmap
+    from mi3dgs import undistort as ud
+    w, h = 240, 160
+    K = np.array([210.0, 205.0, 121.0, 79.0])
+    dist = np.array([-0.14, 0.03, 0.001, -0.002])
+    cams = [io_colmap.Camera(1, "OPENCV", w, h, np.concatenate([K, dist]))]
+    rng = np.random.default_rng(0)
+    os.makedirs(tmp_path / "images")
+    ims, pix = [], {}
+    for i in range(3):
+        name = f"v{i}.png"
+        pix[name] = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        Image.fromarray(pix[name]).save(tmp_path / "images" / name)
+        ims.append(io_colmap.Image(i + 1, np.array([1.0, 0, 0, 0]), np.array([0.1 * i, 0, 2.0]), 1, name))
+    io_colmap.write_model(str(tmp_path / "sparse" / "0"), cams, ims, rng.normal(size=(50, 3)),
+                          rng.integers(0, 255, (50, 3)).astype(np.uint8))
+    ds = dataset.load_colmap_dataset(str(tmp_path), 1)
+    plan = ud.make_plan("OPENCV", dist, K, (w, h))
+    assert (ds.width, ds.height) == plan.out_size and all(p is not None for p in ds.undistort)
+    assert np.allclose(ds.Ks[0].numpy(), [[plan.K_out[0], 0, plan.K_out[2]], [0, plan.K_out[1], plan.K_out[3]], [0, 0, 1]], atol=1e-3)
+    got = ds.load_images([0, 2], DEV, as_u8=True)
+    for j, name in enumerate(("v0.png", "v2.png")):
+        want = PO.undistort_image(pix[name], plan.k_src, plan.k_dst, plan.dist, plan.out_size[1], plan.out_size[0])
+        assert np.abs(got[j].cpu().numpy().astype(np.float64) - want).max() < 0.76
+    f = ds.load_images([1], DEV)
+    assert f.dtype == torch.float32 and f.shape == (1, plan.out_size[1], plan.out_size[0], 3) and float(f.max()) <= 1.0
+    # opting out keeps the files as they are (and says so)
+    raw = dataset.load_colmap_dataset(str(tmp_path), 1, undistort=False)
+    assert (raw.width, raw.height) == (w, h) and torch.equal(raw.load_images([0], DEV, as_u8=True)[0].cpu(), torch.from_numpy(pix["v0.png"]))
