@@ -70,7 +70,7 @@ int mi3dgs_project_fwd(int C, int N, const float* means, const float* quats, con
                        const float* colors, int color_mode, int sh_degree, const float* viewmats,
                        const float* Ks, int width, int height, float eps2d, float near_plane,
                        float far_plane, float radius_clip, int flags, int32_t* radii, float* splats,
-                       void* stream);
+                       uint32_t* depth_keys_opt, void* stream);
 
 /* Replaces fully_fused_projection_bwd + spherical_harmonics_bwd + the autograd of the
  * glue.  v_splats is the packed gradient record written by rasterize_bwd.  Every output is
@@ -131,12 +131,16 @@ int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int
 /* Both phases in one call for callers that bring a capacity (no count to read back): depth sort,
  * then counting and emission fused in one chained pass over the depth-sorted splats (no separate
  * tile_count / scan, the row tables are built once).  Outputs as above; n_isect_dev receives the
- * (uncapped) number of intersections, tiles_per_gauss_opt[C*N] is nullable. */
+ * (uncapped) number of intersections, tiles_per_gauss_opt[C*N] is nullable.  depth_keys_opt[C*N]
+ * (nullable): the sort keys mi3dgs_project_fwd wrote (depth bits, 0xFFFFFFFF for culled splats);
+ * CONSUMED (the sort ping-pongs through the buffer).  Without it the keys are gathered from the
+ * splat records. */
 int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float* splats, int tile_size,
                      int tile_width, int tile_height, int height, int tight,
                      int32_t* n_isect_dev, long long max_isect,
                      int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
                      int64_t* isect_ids_opt, int32_t* tiles_per_gauss_opt,
+                     uint32_t* depth_keys_opt,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* building blocks of the above, exported for reuse and for tests */

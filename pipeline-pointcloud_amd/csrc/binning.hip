@@ -206,7 +206,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
+        val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
     }
     const uint32_t my_global = hist_scanned[threadIdx.x * B + blockIdx.x];     // digit = threadIdx.x
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
+        val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
     }
     const uint32_t my_ghist = ghist_pass[threadIdx.x];
 #pragma unroll
@@ -434,7 +434,8 @@ size_t rs_tmp_u32(uint32_t cap) {
 // LSD radix sort of (key,val) u32 pairs on bits [0, nbits).  Result ends up in (keys_a, vals_a)
 // if the number of passes is even, else in (keys_b, vals_b); returns via *result_in_b.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr,
-                     uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what = "sort") {
+                     uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what = "sort",
+                     bool identity_vals = false) {
     // profiler tags carry the caller's name so the 2M-key depth sort and the I-key tile sort stay apart
     static thread_local char htag_buf[48], ctag_buf[48], s0[48], s1[48], s2[48];
     snprintf(htag_buf, sizeof(htag_buf), "rs_hist/%s", what);
@@ -465,7 +466,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
-            MI_LAUNCH(ctag, os_pass_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n_ptr, cap, shift, mask,
+            MI_LAUNCH(ctag, os_pass_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
                       ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
@@ -484,7 +485,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
         int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, stag3);
         if (rc) return rc;
-        MI_LAUNCH(ctag, rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n_ptr, cap, shift, mask,
+        MI_LAUNCH(ctag, rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
                            hist, B);
         MI_LAUNCH_CHECK();
         uint32_t* t;
@@ -1026,8 +1027,8 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
 extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float* splats, int tile_size, int tile_width,
                                 int tile_height, int height, int tight, int32_t* n_isect_dev, long long max_isect,
                                 int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
-                                int64_t* isect_ids_opt, int32_t* tiles_per_gauss_opt, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                int64_t* isect_ids_opt, int32_t* tiles_per_gauss_opt, uint32_t* depth_keys_opt,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     long long CNl = (long long)C * N;
     MI_REQUIRE(CNl < (1ll << 31), "bin_tiles: C*N must be < 2^31");
     MI_REQUIRE((long long)C * tile_width * tile_height < (1ll << 31), "bin_tiles: too many tiles");
@@ -1047,10 +1048,15 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     size_t need = bin_ws_layout(CN, cap, (uint32_t*)workspace, &ws);
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_tiles: workspace too small");
     MI_REQUIRE(flatten_ids && tile_keys, "bin_tiles: null output");
-    MI_LAUNCH("depth_keys", depth_keys_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, ws.dkeys_a,
-              ws.ids_a);
+    // depth keys: handed in by mi3dgs_project_fwd (consumed: the sort ping-pongs through them), or
+    // gathered from the splat records here; the payload of the first pass is the index itself
+    uint32_t* dkeys = depth_keys_opt ? depth_keys_opt : ws.dkeys_a;
+    if (!depth_keys_opt)
+        MI_LAUNCH("depth_keys", depth_keys_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, dkeys,
+                  ws.ids_a);
     int in_b = 0;
-    int rc = radix_sort_pairs(ws.dkeys_a, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth");
+    int rc = radix_sort_pairs(dkeys, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth",
+                              /*identity_vals=*/depth_keys_opt != nullptr);
     if (rc) return rc;
     const uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
     // chain state lives in the (unused here) `cum` array: status[nblocks] u64 | counter | err

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float* __restrict__ sh0, const float* __restrict__ shN, const float* __restrict__ colors,
     int color_mode, int sh_degree, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     int W, int H, float eps2d, float near_plane, float far_plane, float radius_clip, int flags,
-    int32_t* __restrict__ radii, float* __restrict__ splats) {
+    int32_t* __restrict__ radii, float* __restrict__ splats, uint32_t* __restrict__ depth_keys) {
     // Each wave's 64 Gaussians own one contiguous 11 520-byte slice of shN.  Reading it as
     // 45 dword loads per lane at a 180-byte stride made the first version latency/TA bound
     // (62 VMEM instructions per wave); instead the wave copies the slice with 16-byte loads
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         *rad = make_int2(0, 0);
         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         rec[0] = z4; rec[1] = z4; rec[2] = z4; rec[3] = z4;
+        if (depth_keys) depth_keys[idx] = 0xFFFFFFFFu;      // culled: sorts last
         return;
     }
     float rgb[3];
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     rec[1] = make_float4(P.conC, opa, rgb[0], rgb[1]);
     rec[2] = make_float4(rgb[2], P.mc[2], P.comp, 0.f);
     rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (depth_keys) depth_keys[idx] = __float_as_uint(P.mc[2]);   // depth > 0: the bit pattern orders like the value
 }
 
 // -------------------------------------------------------------------------- backward
@@ -804,7 +806,7 @@ extern "C" int mi3dgs_project_fwd(int C, int N, const float* means, const float*
                                   const float* colors, int color_mode, int sh_degree, const float* viewmats,
                                   const float* Ks, int width, int height, float eps2d, float near_plane,
                                   float far_plane, float radius_clip, int flags, int32_t* radii, float* splats,
-                                  void* stream) {
+                                  uint32_t* depth_keys_opt, void* stream) {
     MI_REQUIRE(C > 0 && N >= 0 && width > 0 && height > 0, "project_fwd: bad sizes");
     MI_REQUIRE(color_mode >= 0 && color_mode <= 2, "project_fwd: color_mode must be 0, 1 or 2");
     MI_REQUIRE(color_mode != 0 || (sh_degree >= 0 && sh_degree <= 3 && sh0 && (sh_degree == 0 || shN)),
@@ -814,7 +816,7 @@ extern "C" int mi3dgs_project_fwd(int C, int N, const float* means, const float*
     long long total = (long long)C * N;
     MI_LAUNCH("project_fwd", project_fwd_kernel, dim3(mi_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, C, N, means,
                        quats, scales, opacities, sh0, shN, colors, color_mode, sh_degree, viewmats, Ks, width, height,
-                       eps2d, near_plane, far_plane, radius_clip, flags, radii, splats);
+                       eps2d, near_plane, far_plane, radius_clip, flags, radii, splats, depth_keys_opt);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -30,7 +30,7 @@ _SIGNATURES = {
     "mi3dgs_profile_enable": (_i, [_i]),
     "mi3dgs_profile_read": (_sz, [C.c_char_p, _sz]),
     "mi3dgs_project_fwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _fl, _fl, _fl, _i,
-                                _f, _f, _f]),
+                                _f, _f, _f, _f]),
     "mi3dgs_project_bwd": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
                                 _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f]),
     "mi3dgs_project_bwd_adam": (_i, [_i, _f, _f, _f, _f, _f, _f, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
@@ -39,7 +39,7 @@ _SIGNATURES = {
     "mi3dgs_bin_workspace_bytes": (_sz, [_i, _i, _ll]),
     "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
     "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),
-    "mi3dgs_bin_tiles": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _f, _sz, _f]),
+    "mi3dgs_bin_tiles": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _sz, _f]),
     "mi3dgs_sort_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_debug_set_sort_mode": (_i, [_i]),
@@ -87,7 +87,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)     # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if handle.mi3dgs_abi_version() != 1:
+        if handle.mi3dgs_abi_version() != 2:
             raise Mi3dgsError("libmi3dgs.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -62,7 +62,7 @@ def workspace(nbytes: int, device, tag: str = "bin") -> torch.Tensor:
 # ------------------------------------------------------------------------------- stages
 def project_fwd(means, quats, scales, opacities, viewmats, Ks, width, height, *, sh0=None, shN=None,
                 colors=None, sh_degree=0, eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
-                flags=0, radii=None, splats=None):
+                flags=0, radii=None, splats=None, depth_keys=None):
     N, Cn = means.shape[0], viewmats.shape[0]
     dev = means.device
     _chk(means, "means", (N, 3)); _chk(quats, "quats", (N, 4)); _chk(scales, "scales", (N, 3))
@@ -84,7 +84,7 @@ def project_fwd(means, quats, scales, opacities, viewmats, Ks, width, height, *,
     _lib.call("mi3dgs_project_fwd", Cn, N, _p(means), _p(quats), _p(scales), _p(opacities), _p(sh0), _p(shN),
               _p(colors), mode, int(sh_degree), _p(viewmats), _p(Ks), int(width), int(height), float(eps2d),
               float(near_plane), float(min(far_plane, 3.0e38)), float(radius_clip), int(flags), _p(radii),
-              _p(splats), _stream(dev))
+              _p(splats), _p(depth_keys), _stream(dev))
     return radii, splats
 
 
@@ -144,12 +144,13 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
               want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False,
-              fused: bool = True):
+              fused: bool = True, depth_keys: Optional[torch.Tensor] = None):
     """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops
     the (tile, splat) pairs the ellipse sigma <= ln(255 o) cannot reach (identical renders and
     gradients, fewer intersections).  With max_isect=None the intersection count is read back (one host
     sync) and the outputs are sized exactly; otherwise outputs hold max_isect entries and
-    the live count stays on the device (no sync)."""
+    the live count stays on the device (no sync).  depth_keys [C,N] int32 (fused path only): the sort
+    keys mi3dgs_project_fwd wrote beside its records; they are consumed."""
     Cn, N = radii.shape[0], radii.shape[1]
     dev = radii.device
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
@@ -168,8 +169,8 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
         offsets = torch.empty(Cn, th, tw, dtype=torch.int32, device=dev)
         isect_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
         _lib.call("mi3dgs_bin_tiles", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
-                  _p(n_isect), cap, _p(flatten_ids), _p(tile_keys), _p(offsets), _p(isect_ids), _p(tpg), _p(ws),
-                  ws.numel(), st)
+                  _p(n_isect), cap, _p(flatten_ids), _p(tile_keys), _p(offsets), _p(isect_ids), _p(tpg), _p(depth_keys),
+                  _p(ws), ws.numel(), st)
         out = dict(n_isect=n_isect, flatten_ids=flatten_ids, tile_keys=tile_keys, isect_offsets=offsets,
                    tile_width=tw, tile_height=th, max_isect=cap)
         if want_isect_ids:

@@ -138,6 +138,7 @@ class Trainer:
         cap = self.model.capacity
         self.radii = torch.empty(1, cap, 2, dtype=torch.int32, device=dev)
         self.splats = torch.empty(1, cap, ops.SPLAT_STRIDE, dtype=torch.float32, device=dev)
+        self.depth_keys = torch.empty(1, cap, dtype=torch.int32, device=dev)
         self.v_splats = torch.zeros(1, cap, ops.GRAD_STRIDE, dtype=torch.float32, device=dev)
         self.raster_out: Dict = {}
         self.loss_scratch: Dict = {}
@@ -211,11 +212,13 @@ class Trainer:
     def _forward(self, viewmat, K, sh_degree, background=None):
         m, n = self.model, self._n()
         radii, splats = self.radii[:, :n], self.splats[:, :n]
+        # with a capacity the binning is one fused call that takes its sort keys straight from the projection
+        keys = self.depth_keys[:, :n] if (self.cfg.fused_binning and self.cfg.max_isect is not None) else None
         ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
-                        far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats)
+                        far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles,
-                                fused=self.cfg.fused_binning)
+                                fused=self.cfg.fused_binning, depth_keys=keys)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids

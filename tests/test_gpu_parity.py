@@ -136,10 +136,19 @@ def test_fused_binning_equals_the_two_phase_path(dev, tight, n, n_views, big):
     ref = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, want_isect_ids=True, want_tiles_per_gauss=True, tight=tight)
     I = int(ref["n_isect"].item())
     assert I > 0
+    # sort keys straight from the projection (consumed by the fused call, so a fresh copy each time)
+    keys = torch.empty(radii.shape[:2], dtype=torch.int32, device=dev)
+    r2, s2 = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                             g.viewmats, g.Ks, sc.width, sc.height, sh0=g.params["sh0"], shN=g.params["shN"],
+                             sh_degree=3, flags=3, depth_keys=keys)
+    assert torch.equal(r2, radii) and torch.equal(s2, splats)
+    vis = (radii > 0).all(-1)
+    assert torch.equal(keys[vis], splats[..., 9][vis].view(torch.int32)) and bool((keys[~vis] == -1).all())
     for cap in (I + 777, I, max(I // 2, 1)):                 # roomy, exact, overflowing capacity
-        for fused in (True, False):
+        for fused in (True, False, "keys"):
             b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=cap, want_isect_ids=True,
-                              want_tiles_per_gauss=True, tight=tight, fused=fused)
+                              want_tiles_per_gauss=True, tight=tight, fused=bool(fused),
+                              depth_keys=keys.clone() if fused == "keys" else None)
             assert int(b["n_isect"].item()) == I
             assert torch.equal(b["tiles_per_gauss"], ref["tiles_per_gauss"])
             if cap >= I:
