@@ -281,6 +281,80 @@ class Trainer:
             return float(ops.loss_value(sums, self.H * self.W * 3, c.ssim_lambda))
         return None
 
+    # -- HBM placement of the parameter / moment arrays ------------------------------------
+    @torch.no_grad()
+    def tune_placement(self, sweeps: int = 4, min_gain: float = 0.003, log=None) -> Dict[str, float]:
+        """The fused backward+Adam kernel streams 18 arrays (6 groups x parameter / exp_avg /
+        exp_avg_sq) at once, and its speed depends on which physical pages each of them got: 576 to
+        677 us on identical code and addresses ("placement").  This walks the arrays of
+        both banks, gives each a few alternative allocations, times the kernel itself on every
+        candidate and keeps the best.  The kernel runs as an exact no-op while it is timed (zero
+        gradients, zero moments, zero learning rates), so it must be called before the first step.
+        Costs a few hundred milliseconds and, transiently, a few GB."""
+        c, m = self.cfg, self.model
+        if not (c.fuse_adam and self._can_fuse_adam()) or m.n == 0 or self.step_count != 0:
+            return {}
+        n = m.n
+        viewmat, K = self.viewmats[:1], self.Ks[:1]
+        sd = c.sh_degree
+        self._forward(viewmat, K, sd)                        # fills self.radii / self.splats for one real view
+        self.v_splats.zero_()
+        track = c.densify
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def run(bank):
+            ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
+                                 [bank[g]["v"] for g in GROUPS], (0.0,) * 6, 1, viewmat, K, self.W, self.H,
+                                 self.radii[:, :n], self.splats[:, :n], self.v_splats[:, :n], n=n, sh_degree=sd,
+                                 flags=self._flags(), beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                                 stats={k: v[:n] for k, v in self.stats.items()} if track else None,
+                                 stat_use_abs=c.absgrad)
+
+        def timed(bank) -> float:
+            best = float("inf")
+            run(bank)
+            for _ in range(3):
+                e0.record()
+                run(bank)
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+
+        report, graveyard = {}, []
+        shared = [(self.__dict__, k) for k in ("splats", "v_splats", "radii")] + [(self.stats, k) for k in self.stats]
+        for b, bank in enumerate(m.banks):
+            if b != m.cur:                       # the spare bank has to hold real parameters while it is timed
+                for g in GROUPS:
+                    bank[g]["p"].copy_(m.banks[m.cur][g]["p"])
+            t_best = t_first = timed(bank)
+            slots = [(bank[g], k) for g in GROUPS for k in ("p", "m", "v")] + (shared if b == m.cur else [])
+            for _ in range(sweeps):
+                for holder, key in slots:
+                    old = holder[key]
+                    new = torch.empty_like(old)              # fresh pages: `old` is still held
+                    new.copy_(old)
+                    holder[key] = new
+                    t = timed(bank)
+                    if t < t_best * (1.0 - min_gain):
+                        t_best = t
+                        graveyard.append(old)
+                    else:
+                        holder[key] = old
+                        graveyard.append(new)
+            report[f"bank{b}_first_us"], report[f"bank{b}_tuned_us"] = t_first * 1e3, t_best * 1e3
+            if b != m.cur:
+                for g in GROUPS:
+                    bank[g]["p"].zero_()
+        for v in self.stats.values():             # the timed launches counted visibility; nothing else changed
+            v.zero_()
+        del graveyard
+        torch.cuda.empty_cache()
+        if log is not None:
+            log("placement: fused backward " + ", ".join(
+                f"bank {b} {report[f'bank{b}_first_us']:.0f} -> {report[f'bank{b}_tuned_us']:.0f} us" for b in range(len(m.banks))))
+        return report
+
     def _all_reduce_grads(self):
         """Hook for the replicated-Gaussian data-parallel mode (parallel.py); no-op on one GPU."""
         return

@@ -536,3 +536,31 @@ def test_mcmc_trainer_relocates_and_grows(dev):
         tr.step(s % 4)
     assert tr.model.n == 1200                                       # capped at cap_max
     assert all(torch.isfinite(tr.model.p(k)).all() for k in trainer.GROUPS)
+
+
+def test_placement_tuning_is_a_no_op_on_the_model(dev):
+    """tune_placement() re-allocates arrays and times the fused kernel as an exact no-op: parameters, moments and
+    densify statistics are what they were, and training afterwards is what it would have been."""
+    from mi3dgs import trainer
+    sc = small_scene(n=3000, seed=41, width=96, height=64, n_views=2).to(dev)
+    imgs = torch.rand(2, 64, 96, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    runs = []
+    for tune in (False, True):
+        tr = trainer.Trainer({k: v.clone() for k, v in sc.params.items()}, sc.viewmats, sc.Ks, imgs, 96, 64,
+                             trainer.TrainConfig(capacity=4000, refine_start_iter=10 ** 9))
+        before = {g: tr.model.p(g).clone() for g in trainer.GROUPS}
+        if tune:
+            rep = tr.tune_placement(sweeps=1)
+            assert rep["bank0_tuned_us"] <= rep["bank0_first_us"] and "bank1_tuned_us" in rep
+            for g in trainer.GROUPS:
+                assert torch.equal(tr.model.p(g), before[g])
+                for b in range(2):
+                    assert float(tr.model.banks[b][g]["m"].abs().max()) == 0 and float(tr.model.banks[b][g]["v"].abs().max()) == 0
+                assert float(tr.model.banks[1 - tr.model.cur][g]["p"].abs().max()) == 0
+            assert all(float(v.abs().max()) == 0 for v in tr.stats.values())
+            assert tr.tune_placement() == {} or tr.step_count == 0      # refuses once training has begun (below)
+        losses = [tr.step(i % 2, want_loss=True) for i in range(5)]
+        assert tr.tune_placement() == {}
+        runs.append((losses, tr.model.p("means").clone(), tr.stats["count"].clone()))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and torch.allclose(runs[0][1], runs[1][1], atol=1e-6)
+    assert torch.equal(runs[0][2], runs[1][2])
