@@ -563,7 +563,7 @@ __device__ __attribute__((noinline)) void row_span(const SpanGeom& g, int ty, in
 // binary search over g's rows.  (A first version walked the rows from the top for every emitted
 // key: 656 us instead of 87 for tile_emit.)  Splats whose rows do not fit the pool (more than
 // ROW_POOL rows in one block: rare, huge splats) are flagged `slow` and use the row walk.
-constexpr int ROW_POOL = 4096;
+constexpr int ROW_POOL = 2048;
 
 struct RowTable {
     uint32_t row_base[257];        // exclusive scan of rows per splat, [256] = total
