@@ -54,70 +54,130 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* to
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n,
-                                                                   uint32_t* __restrict__ sums) {
-    __shared__ uint32_t lds4[4];
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 24;
+
+// ---- single-value decoupled look-back (chained scan) (used by the device-wide scan and by the fused count+emit kernel).  One
+// 64-bit word per block {flag:2 (bits 32..33) | value:32}: flag 1 = the block's own total,
+// 2 = inclusive prefix; zero (the memset state) = not there yet.  Block ids are handed out by an
+// atomic counter, so every predecessor is already running and each wait ends.  Wave 0 calls this
+// with all 64 lanes and inspects 64 predecessors per step.  Agent-scope atomics: the per-XCD L2s
+// are not coherent with one another.
+__device__ __forceinline__ unsigned long long chain_pack(uint32_t flag, uint32_t v) {
+    return ((unsigned long long)flag << 32) | v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) s += in[base + i];
-    s = wave_sum_all_u32(s);
-    if (lane_id() == 0) lds4[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
-
-// single block: exclusive scan of sums[0..nb) in place, total -> *total_out (may be null)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(uint32_t* __restrict__ sums, uint32_t nb,
-                                                                 uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t lds4[4];
-    uint32_t carry = 0;
-    for (uint32_t start = 0; start < nb; start += SCAN_THREADS) {
-        uint32_t i = start + threadIdx.x;
-        uint32_t v = i < nb ? sums[i] : 0;
-        uint32_t tot;
-        uint32_t ex = block_excl_scan_u32(v, &tot, lds4);
-        if (i < nb) sums[i] = carry + ex;
-        carry += tot;
+__device__ __forceinline__ uint32_t chain_lookback(unsigned long long* status, uint32_t blk, uint32_t total, int lane,
+                                                   uint32_t* err) {
+    if (lane == 0)
+        __hip_atomic_store(status + blk, chain_pack(blk == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    if (blk > 0) {
+        int p = (int)blk - 1;
+        while (true) {
+            int idx = p - lane;
+            unsigned long long w = chain_pack(2u, 0u);              // before block 0: prefix 0
+            if (idx >= 0) {
+                unsigned spins = 0;
+                while (true) {
+                    w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((w >> 32) & 3ull) != 0ull) break;
+                    if (++spins > CHAIN_SPIN_LIMIT) { atomicOr(err, 2u); w = chain_pack(2u, 0u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            uint32_t val = (uint32_t)w;
+            unsigned long long pm = __ballot(((w >> 32) & 3ull) == 2ull);
+            if (pm) {
+                int f = __ffsll((long long)pm) - 1;                  // nearest predecessor holding a prefix
+                excl += wave_sum_u32(lane <= f ? val : 0u);
+                break;
+            }
+            excl += wave_sum_u32(val);
+            p -= 64;
+        }
+        if (lane == 0)
+            __hip_atomic_store(status + blk, chain_pack(2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    return excl;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t* __restrict__ in, uint32_t n,
-                                                                  const uint32_t* __restrict__ sums,
-                                                                  uint32_t* __restrict__ out) {
+// Device-wide exclusive scan in ONE launch: a block scans its 4 096-element tile in registers, chains
+// its total through `status` (decoupled look-back) and writes.  Replaces reduce / scan-of-sums /
+// final (three launches, ~30 us for the 950 k block-histogram counters of a radix pass).
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chained_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                                    uint32_t* __restrict__ out,
+                                                                    unsigned long long* status, uint32_t* counter,
+                                                                    uint32_t* err, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t lds4[4];
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    __shared__ uint32_t s_blk, s_base;
+    if (threadIdx.x == 0) s_blk = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t blk = s_blk;
+    uint32_t base = blk * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
+    if (base + SCAN_ITEMS <= n && ((uintptr_t)in & 15) == 0) {
+        const uint4* i4 = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        v[i] = (base + i < n) ? in[base + i] : 0;
-        s += v[i];
+        for (int i = 0; i < SCAN_ITEMS / 4; i++) {
+            uint4 q = i4[i];
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : 0;
     }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan_u32(s, &tot, lds4) + sums[blockIdx.x];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (base + i < n) out[base + i] = ex;
-        ex += v[i];
+    for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_u32(s, &tot, lds4);
+    if (threadIdx.x < 64) {
+        uint32_t excl = chain_lookback(status, blk, tot, (int)threadIdx.x, err);
+        if (threadIdx.x == 0) {
+            s_base = excl;
+            if (blk == gridDim.x - 1 && total_out) *total_out = excl + tot;
+        }
+    }
+    __syncthreads();
+    ex += s_base;
+    if (base + SCAN_ITEMS <= n && ((uintptr_t)out & 15) == 0) {
+        uint4* o4 = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS / 4; i++) {
+            uint4 q;
+            q.x = ex; ex += v[4 * i];
+            q.y = ex; ex += v[4 * i + 1];
+            q.z = ex; ex += v[4 * i + 2];
+            q.w = ex; ex += v[4 * i + 3];
+            o4[i] = q;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (base + i < n) out[base + i] = ex;
+            ex += v[i];
+        }
     }
 }
 
-// exclusive scan; tmp needs div_up(n, SCAN_TILE) u32.  in may equal out.
+// u32 words of scratch the scan needs for n elements: status[nb] u64 | counter | err (+ slack)
+inline size_t scan_tmp_u32(size_t n) { return 2 * (size_t)mi_div_up((long long)n, SCAN_TILE) + 16; }
+
+// exclusive scan; tmp needs scan_tmp_u32(n) u32, 8-byte aligned.  in may equal out.
 int scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tmp, uint32_t* total_out,
-                       hipStream_t st, const char* const* stag = nullptr) {
-    static const char* const dflt[3] = {"scan_reduce", "scan_sums", "scan_final"};
-    if (!stag) stag = dflt;
+                       hipStream_t st, const char* tag = "scan") {
     if (n == 0) {
         if (total_out) MI_HIP(hipMemsetAsync(total_out, 0, 4, st));
         return 0;
     }
     uint32_t nb = mi_div_up(n, SCAN_TILE);
-    MI_LAUNCH(stag[0], scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
-    MI_LAUNCH(stag[1], scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tmp, nb, total_out);
-    MI_LAUNCH(stag[2], scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, tmp, out);
+    MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)2 * nb + 2) * sizeof(uint32_t), st));
+    MI_LAUNCH(tag, scan_chained_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, out,
+              reinterpret_cast<unsigned long long*>(tmp), tmp + 2 * (size_t)nb, tmp + 2 * (size_t)nb + 1, total_out);
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -273,7 +333,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 //   workgroup that has already started: the chain always resolves, whatever the residency.
 //   Every spin is bounded; a timeout raises *err and lets the grid drain.
 constexpr int OS_MAX_PASSES = 4;
-constexpr unsigned OS_SPIN_LIMIT = 1u << 24;
+constexpr unsigned OS_SPIN_LIMIT = CHAIN_SPIN_LIMIT;
 
 __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap, int passes,
@@ -426,7 +486,7 @@ constexpr uint32_t OS_MAX_KEYS = 4u << 20;
 size_t rs_tmp_u32(uint32_t cap) {
     uint32_t B = mi_div_up(cap, RS_TILE);
     size_t hist = (size_t)256 * B;
-    size_t classic = hist + mi_div_up(hist, SCAN_TILE) + 16;
+    size_t classic = hist + scan_tmp_u32(hist);
     size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + 2 * hist + 16;
     return classic > onesweep ? classic : onesweep;
 }
@@ -437,15 +497,12 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
                      uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what = "sort",
                      bool identity_vals = false) {
     // profiler tags carry the caller's name so the 2M-key depth sort and the I-key tile sort stay apart
-    static thread_local char htag_buf[48], ctag_buf[48], s0[48], s1[48], s2[48];
+    static thread_local char htag_buf[48], ctag_buf[48], s0[48];
     snprintf(htag_buf, sizeof(htag_buf), "rs_hist/%s", what);
     snprintf(ctag_buf, sizeof(ctag_buf), "rs_scatter/%s", what);
-    snprintf(s0, sizeof(s0), "scan_reduce/%s", what);
-    snprintf(s1, sizeof(s1), "scan_sums/%s", what);
-    snprintf(s2, sizeof(s2), "scan_final/%s", what);
+    snprintf(s0, sizeof(s0), "scan/%s", what);
     const char* htag = htag_buf;
     const char* ctag = ctag_buf;
-    const char* const stag3[3] = {s0, s1, s2};
     *result_in_b = 0;
     if (cap == 0 || nbits <= 0) return 0;
     uint32_t B = mi_div_up(cap, RS_TILE);
@@ -483,7 +540,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         int bits = (shift + per <= nbits) ? per : (nbits - shift);
         uint32_t mask = (1u << bits) - 1u;
         MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
-        int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, stag3);
+        int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, s0);
         if (rc) return rc;
         MI_LAUNCH(ctag, rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
                            hist, B);
@@ -688,55 +745,6 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(uint32_t CN, const int3
     ids[idx] = idx;
 }
 
-// ---- single-value decoupled look-back (chained scan) for the fused count+emit kernel.  One
-// 64-bit word per block {flag:2 (bits 32..33) | value:32}: flag 1 = the block's own total,
-// 2 = inclusive prefix; zero (the memset state) = not there yet.  Block ids are handed out by an
-// atomic counter, so every predecessor is already running and each wait ends.  Wave 0 calls this
-// with all 64 lanes and inspects 64 predecessors per step.  Agent-scope atomics: the per-XCD L2s
-// are not coherent with one another.
-__device__ __forceinline__ unsigned long long chain_pack(uint32_t flag, uint32_t v) {
-    return ((unsigned long long)flag << 32) | v;
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t chain_lookback(unsigned long long* status, uint32_t blk, uint32_t total, int lane,
-                                                   uint32_t* err) {
-    if (lane == 0)
-        __hip_atomic_store(status + blk, chain_pack(blk == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0;
-    if (blk > 0) {
-        int p = (int)blk - 1;
-        while (true) {
-            int idx = p - lane;
-            unsigned long long w = chain_pack(2u, 0u);              // before block 0: prefix 0
-            if (idx >= 0) {
-                unsigned spins = 0;
-                while (true) {
-                    w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (((w >> 32) & 3ull) != 0ull) break;
-                    if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 2u); w = chain_pack(2u, 0u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            uint32_t val = (uint32_t)w;
-            unsigned long long pm = __ballot(((w >> 32) & 3ull) == 2ull);
-            if (pm) {
-                int f = __ffsll((long long)pm) - 1;                  // nearest predecessor holding a prefix
-                excl += wave_sum_u32(lane <= f ? val : 0u);
-                break;
-            }
-            excl += wave_sum_u32(val);
-            p -= 64;
-        }
-        if (lane == 0)
-            __hip_atomic_store(status + blk, chain_pack(2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return excl;
-}
-
 // CHAINED = false: offsets come from `cum` (mi3dgs_bin_count ran tile_count + gather + scan before).
 // CHAINED = true : count and emit in ONE pass over the depth-sorted splats: the block builds its row
 // table once, chains its total through `status`, and emits; tile_count, the gather and the
@@ -915,7 +923,7 @@ size_t bin_ws_layout(uint32_t CN, uint32_t cap, uint32_t* base, BinWs* ws) {
     uint32_t* ib = take(CN);
     uint32_t* cum = take(CN);
     uint32_t* ni = take(16);
-    size_t t1 = rs_tmp_u32(CN), t2 = rs_tmp_u32(cap), t3 = mi_div_up(CN, SCAN_TILE) + 16;
+    size_t t1 = rs_tmp_u32(CN), t2 = rs_tmp_u32(cap), t3 = scan_tmp_u32(CN);
     size_t tm = t1 > t2 ? t1 : t2;
     if (t3 > tm) tm = t3;
     uint32_t* tmp = take(tm);
@@ -1106,7 +1114,7 @@ extern "C" int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n
     return 0;
 }
 
-extern "C" size_t mi3dgs_scan_workspace_bytes(long long n) { return ((size_t)mi_div_up(n, SCAN_TILE) + 16) * 4; }
+extern "C" size_t mi3dgs_scan_workspace_bytes(long long n) { return scan_tmp_u32((size_t)(n > 0 ? n : 0)) * 4; }
 
 extern "C" int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* total_dev,
                                          void* workspace, size_t workspace_bytes, void* stream) {
