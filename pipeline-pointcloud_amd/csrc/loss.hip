@@ -42,16 +42,34 @@ __device__ __forceinline__ float block_sum(float v, float* lds4) {
     return s;
 }
 
-// stage the 42x42 halo region of an interleaved [H,W,3] image into 3 channel planes (zero padded)
-__device__ __forceinline__ void stage_planes(const float* __restrict__ img, int H, int W, int x0, int y0,
-                                             float (*plane)[LW][LS]) {
-    for (int i = threadIdx.x; i < LW * ROW3; i += NT) {
+// Staging of the 42x42 halo region of an interleaved [H,W,3] image into 3 channel planes (zero
+// padded), in two steps: ALL global loads of a thread first (into registers), the LDS stores after.
+// The one-step version compiled to load -> s_waitcnt vmcnt(0) -> ds_write per element, i.e. eleven
+// full memory latencies in series per image and block.
+constexpr int ST_ITERS = (LW * ROW3 + NT - 1) / NT;     // elements of one image per thread
+
+__device__ __forceinline__ void stage_load(const float* __restrict__ img, int H, int W, int x0, int y0,
+                                           float (&v)[ST_ITERS]) {
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; it++) {
+        int i = (int)threadIdx.x + it * NT;
+        int r = i / ROW3, j = i - r * ROW3;
+        int y = y0 + r - HALO;
+        int xj = (x0 - HALO) * 3 + j;                      // float index inside the image row: 3 x + channel
+        bool ok = i < LW * ROW3 && y >= 0 && y < H && xj >= 0 && xj < W * 3;
+        int off = ok ? y * (W * 3) + xj : 0;              // 32-bit offset from a uniform base: saddr addressing, one VGPR
+        float val = img[off];
+        v[it] = ok ? val : 0.f;
+    }
+}
+
+__device__ __forceinline__ void stage_store(float (*plane)[LW][LS], const float (&v)[ST_ITERS]) {
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; it++) {
+        int i = (int)threadIdx.x + it * NT;
         int r = i / ROW3, j = i - r * ROW3;
         int col = j / 3, ch = j - col * 3;
-        int y = y0 + r - HALO, x = x0 + col - HALO;
-        float v = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = img[((size_t)y * W + x) * 3 + ch];
-        plane[ch][r][col] = v;
+        if (i < LW * ROW3) plane[ch][r][col] = v[it];
     }
 }
 
@@ -72,8 +90,13 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
     const int cam = blockIdx.z;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const size_t base = (size_t)cam * H * W * 3;
-    stage_planes(img1 + base, H, W, x0, y0, pu);
-    stage_planes(img2 + base, H, W, x0, y0, pv);
+    {
+        float ra[ST_ITERS], rb[ST_ITERS];
+        stage_load(img1 + base, H, W, x0, y0, ra);
+        stage_load(img2 + base, H, W, x0, y0, rb);
+        stage_store(pu, ra);
+        stage_store(pv, rb);
+    }
     __syncthreads();
     const int vc = threadIdx.x & 31, vg = threadIdx.x >> 5;      // vertical pass: column, row group
     float l1 = 0.f, ss = 0.f;
@@ -157,11 +180,28 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
     const int cam = blockIdx.z;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const size_t base = (size_t)cam * H * W * 3;
-    const float* maps[3] = {dm_dmu1 + base, dm_dsig1 + base, dm_dsig12 + base};
+    // every global read of the block goes out first: the three derivative maps and the two image
+    // values of each output pixel
+    float rm[3][ST_ITERS];
+    stage_load(dm_dmu1 + base, H, W, x0, y0, rm[0]);
+    stage_load(dm_dsig1 + base, H, W, x0, y0, rm[1]);
+    stage_load(dm_dsig12 + base, H, W, x0, y0, rm[2]);
+    const int vc = threadIdx.x & 31, vg = threadIdx.x >> 5;
+    float pu_[3][VO], pv_[3][VO];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int o = 0; o < VO; o++) {
+            int px = x0 + vc, py = y0 + vg * VO + o;
+            bool in = px < W && py < H;
+            int off = ((in ? py : 0) * W + (in ? px : 0)) * 3 + ch;
+            pu_[ch][o] = (img1 + base)[off];
+            pv_[ch][o] = (img2 + base)[off];
+        }
 #pragma unroll
     for (int m = 0; m < 3; m++) {
         __syncthreads();
-        stage_planes(maps[m], H, W, x0, y0, pl);
+        stage_store(pl, rm[m]);
         __syncthreads();
         for (int t = threadIdx.x; t < 3 * LW * (LT / 4); t += NT) {
             int ch = t / (LW * (LT / 4));
@@ -180,7 +220,6 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
         }
     }
     __syncthreads();
-    const int vc = threadIdx.x & 31, vg = threadIdx.x >> 5;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         float acc[VO][3];
@@ -200,7 +239,7 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
             int px = x0 + vc, py = y0 + vg * VO + o;
             if (px < W && py < H) {
                 size_t p = base + ((size_t)py * W + px) * 3 + ch;
-                float u = img1[p], v = img2[p];
+                float u = pu_[ch][o], v = pv_[ch][o];
                 float d = u - v;
                 float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
                 v_img1[p] = w_l1 * sgn + w_ssim * (acc[o][0] + 2.f * u * acc[o][1] + v * acc[o][2]);
