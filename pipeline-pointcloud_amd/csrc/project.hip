@@ -509,10 +509,16 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
         if (FUSE) {
             const float4* s4 = reinterpret_cast<const float4*>(shN + 45 * (long long)n0);
             float4* l4 = reinterpret_cast<float4*>(slice);
+            const int n4s = count >> 2;                      // >= 11: a wave holds at least one Gaussian
+            // Loads first, unconditionally (index clamped), LDS stores after.  With the bounds test around
+            // each load the compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write twelve times in a row:
+            // twelve memory latencies in series at the head of every wave.
+#pragma unroll
+            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) keep[j] = s4[min(lane + 64 * j, n4s - 1)];
 #pragma unroll
             for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
                 int i4 = lane + 64 * j;
-                if (i4 < (count >> 2)) { keep[j] = s4[i4]; l4[i4] = keep[j]; }
+                if (i4 < n4s) l4[i4] = keep[j];
             }
             if (lane < (count & 3)) slice[(count & ~3) + lane] = shN[45 * (long long)n0 + (count & ~3) + lane];
         } else {
@@ -626,22 +632,52 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
                         vs[i] += (sl[i] == mx ? gg / (float)nmx : 0.f) - (sl[i] == mn ? gg / (float)nmn : 0.f);
                 }
             }
-#define MI_ADAM_ROW(GRP, PTR, W, GRADS)                                                                      \
-            {                                                                                                \
-                _Pragma("unroll") for (int i = 0; i < (W); i++) {                                            \
-                    long long o = (long long)(W) * n + i;                                                    \
-                    float pp = (PTR)[o], mm = A.m[GRP][o], vv = A.v[GRP][o];                                 \
-                    mi_adam1(pp, (GRADS)[i], mm, vv, A.step_size[GRP], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);   \
-                    (PTR)[o] = pp; A.m[GRP][o] = mm; A.v[GRP][o] = vv;                                       \
-                }                                                                                            \
+// All 42 loads (parameter, exp_avg, exp_avg_sq of the 14 small-group values) first, then the
+            // arithmetic, then the stores.  Row by row, the possible aliasing between the parameter and
+            // moment pointers kept every row's loads behind the previous row's stores: fourteen more
+            // memory latencies in series.
+            // (a missing opacity array is read through `means` so that the load section has no branch, and skipped when storing)
+            const bool has_opa = opacities != nullptr;
+            float* const P_[5] = {means, quats, scales, has_opa ? opacities : means, A.sh0};
+            float* const M_[5] = {A.m[0], A.m[1], A.m[2], has_opa ? A.m[3] : means, A.m[4]};
+            float* const V_[5] = {A.v[0], A.v[1], A.v[2], has_opa ? A.v[3] : means, A.v[4]};
+            constexpr int W_[5] = {3, 4, 3, 1, 3};
+            float pp[14], mm[14], vv[14];
+            {
+                int e = 0;
+#pragma unroll
+                for (int gi = 0; gi < 5; gi++) {
+#pragma unroll
+                    for (int i = 0; i < W_[gi]; i++, e++) {
+                        long long o = (long long)W_[gi] * n + i;
+                        pp[e] = P_[gi][o];
+                        mm[e] = M_[gi][o];
+                        vv[e] = V_[gi][o];
+                    }
+                }
             }
-            float gop[1] = {G.vopa};
-            MI_ADAM_ROW(0, means, 3, G.vmean)
-            MI_ADAM_ROW(1, quats, 4, vq)
-            MI_ADAM_ROW(2, scales, 3, vs)
-            if (opacities) MI_ADAM_ROW(3, opacities, 1, gop)
-            MI_ADAM_ROW(4, A.sh0, 3, vc0)
-#undef MI_ADAM_ROW
+            const float gsm[14] = {G.vmean[0], G.vmean[1], G.vmean[2], vq[0], vq[1], vq[2], vq[3], vs[0], vs[1], vs[2],
+                                   G.vopa, vc0[0], vc0[1], vc0[2]};
+            {
+                int e = 0;
+#pragma unroll
+                for (int gi = 0; gi < 5; gi++) {
+#pragma unroll
+                    for (int i = 0; i < W_[gi]; i++, e++)
+                        mi_adam1(pp[e], gsm[e], mm[e], vv[e], A.step_size[gi], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                }
+            }
+            {
+                int e = 0;
+#pragma unroll
+                for (int gi = 0; gi < 5; gi++) {
+#pragma unroll
+                    for (int i = 0; i < W_[gi]; i++, e++) {
+                        long long o = (long long)W_[gi] * n + i;
+                        if (gi != 3 || has_opa) { P_[gi][o] = pp[e]; M_[gi][o] = mm[e]; V_[gi][o] = vv[e]; }
+                    }
+                }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -655,16 +691,29 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
         float4* p4 = reinterpret_cast<float4*>(shN + off);
         float4* m4 = reinterpret_cast<float4*>(A.m[5] + off);
         float4* v4 = reinterpret_cast<float4*>(A.v[5] + off);
+        // moments of four float4s per lane in flight at a time (loads, then arithmetic, then stores; see above)
+        constexpr int NJ = (SH_WAVE_F4 + 63) / 64, GJ = 4;
 #pragma unroll
-        for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
-            int i4 = lane + 64 * j;
-            if (i4 < n4) {
-                float4 g = g4[i4], pp = need_coef ? keep[j] : p4[i4], mm = m4[i4], vv = v4[i4];
-                mi_adam1(pp.x, g.x, mm.x, vv.x, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
-                mi_adam1(pp.y, g.y, mm.y, vv.y, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
-                mi_adam1(pp.z, g.z, mm.z, vv.z, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
-                mi_adam1(pp.w, g.w, mm.w, vv.w, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
-                p4[i4] = pp; m4[i4] = mm; v4[i4] = vv;
+        for (int j0 = 0; j0 < NJ; j0 += GJ) {
+            float4 mq[GJ], vq4[GJ], pq[GJ];
+#pragma unroll
+            for (int jj = 0; jj < GJ; jj++) {
+                int i4 = min(lane + 64 * (j0 + jj), n4 - 1);
+                mq[jj] = m4[i4];
+                vq4[jj] = v4[i4];
+                pq[jj] = need_coef ? keep[(j0 + jj) < NJ ? (j0 + jj) : 0] : p4[i4];
+            }
+#pragma unroll
+            for (int jj = 0; jj < GJ; jj++) {
+                int i4 = lane + 64 * (j0 + jj);
+                if (j0 + jj < NJ && i4 < n4) {
+                    float4 g = g4[i4], pp = pq[jj], mm = mq[jj], vv = vq4[jj];
+                    mi_adam1(pp.x, g.x, mm.x, vv.x, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                    mi_adam1(pp.y, g.y, mm.y, vv.y, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                    mi_adam1(pp.z, g.z, mm.z, vv.z, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                    mi_adam1(pp.w, g.w, mm.w, vv.w, A.step_size[5], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                    p4[i4] = pp; m4[i4] = mm; v4[i4] = vv;
+                }
             }
         }
         int rem = count & 3;

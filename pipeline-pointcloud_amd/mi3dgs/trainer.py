@@ -334,7 +334,7 @@ class Trainer:
         best = [timed(bk) for bk in m.banks]
         first = list(best)
         n_vis = int((self.radii[:, :n] > 0).all(-1).sum())
-        target_ms = (n * 1424.0 + n_vis * 128.0) / 5.3e12 * 1e3
+        target_ms = (n * 1424.0 + n_vis * 128.0) / 5.9e12 * 1e3
         # Sweeps alternate between the banks: the candidates of the first sweep all come from the same
         # untouched region of memory and often look alike; later ones land between the blocks the search
         # itself has scattered, which is where the good layouts were found.
@@ -362,7 +362,7 @@ class Trainer:
                     for ob, obank in enumerate(m.banks):
                         if ob != b:
                             best[ob] = timed(obank)
-            # good enough = the kernel's algorithmic bytes at 5.3 TB/s (the best layouts seen reach 5.3-5.4)
+            # good enough = the kernel s algorithmic bytes at 5.9 TB/s (the best layouts seen reach 5.7)
             if max(best) <= target_ms or time.time() - t_start > budget_s:
                 break
         for b in range(len(m.banks)):
