@@ -269,10 +269,15 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         if (whole && (((uintptr_t)src) & 15) == 0 && __ballot(ok) != 0ull) {
             staged = true;
             const float4* s4 = reinterpret_cast<const float4*>(src);
+            // loads first (index clamped, no branch), LDS stores after: with the bounds test around each
+            // copy the compiler serialised them, load -> s_waitcnt vmcnt(0) -> ds_write twelve times
+            float4 tmp[(SH_WAVE_F4 + 63) / 64];
+#pragma unroll
+            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) tmp[j] = s4[min(lane + 64 * j, SH_WAVE_F4 - 1)];
 #pragma unroll
             for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
                 int i4 = lane + 64 * j;
-                if (i4 < SH_WAVE_F4) sSH4[wv][i4] = s4[i4];
+                if (i4 < SH_WAVE_F4) sSH4[wv][i4] = tmp[j];
             }
         }
     }
@@ -436,10 +441,13 @@ __device__ __forceinline__ void slice_load(float* lds, const float* src, int cou
     int n4 = count >> 2;
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* l4 = reinterpret_cast<float4*>(lds);
+    float4 tmp[(SH_WAVE_F4 + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) tmp[j] = s4[min(lane + 64 * j, max(n4 - 1, 0))];   // all loads in flight
 #pragma unroll
     for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
         int i4 = lane + 64 * j;
-        if (i4 < n4) l4[i4] = s4[i4];
+        if (i4 < n4) l4[i4] = tmp[j];
     }
     int rem = count & 3;
     if (lane < rem) lds[4 * n4 + lane] = src[4 * n4 + lane];
