@@ -48,31 +48,43 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, 
     long long base = (long long)(blk - sg.first_block) * AD_PER_BLOCK;
     float step_size = sg.lr * inv_bc1;
     bool aligned = ((((uintptr_t)sg.p) | ((uintptr_t)sg.g) | ((uintptr_t)sg.m) | ((uintptr_t)sg.v)) & 15) == 0;
+    // Fast path (whole block inside an aligned segment): the 16 loads of a thread go out together, then
+    // the arithmetic, then the stores.  Iteration by iteration the stores of one round kept the loads
+    // of the next behind them (the four pointers may alias as far as the compiler knows).
+    if (aligned && base + AD_PER_BLOCK <= sg.n) {
+        f32x4 p[4], g[4], m[4], v[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            long long i = base + ((long long)it * AD_THREADS + threadIdx.x) * 4;
+            // streamed once per step, never re-read before the next step: non-temporal
+            p[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.p + i));
+            g[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.g + i));
+            m[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.m + i));
+            v[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.v + i));
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            long long i = base + ((long long)it * AD_THREADS + threadIdx.x) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float pe = p[it][e], me = m[it][e], ve = v[it][e];
+                adam1(pe, g[it][e], me, ve, step_size, b1, b2, inv_bc2_sqrt, eps);
+                p[it][e] = pe; m[it][e] = me; v[it][e] = ve;
+            }
+            *reinterpret_cast<f32x4*>(sg.p + i) = p[it];     // parameters are re-read by the next forward
+            __builtin_nontemporal_store(m[it], reinterpret_cast<f32x4*>(sg.m + i));
+            __builtin_nontemporal_store(v[it], reinterpret_cast<f32x4*>(sg.v + i));
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         long long i = base + ((long long)it * AD_THREADS + threadIdx.x) * 4;
         if (i >= sg.n) break;
-        if (aligned && i + 4 <= sg.n) {
-            // streamed once per step, never re-read before the next step: non-temporal
-            f32x4 p = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.p + i));
-            f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.g + i));
-            f32x4 m = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.m + i));
-            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sg.v + i));
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float pe = p[e], me = m[e], ve = v[e];
-                adam1(pe, g[e], me, ve, step_size, b1, b2, inv_bc2_sqrt, eps);
-                p[e] = pe; m[e] = me; v[e] = ve;
-            }
-            *reinterpret_cast<f32x4*>(sg.p + i) = p;         // parameters are re-read by the next forward
-            __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(sg.m + i));
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(sg.v + i));
-        } else {
-            for (int k = 0; k < 4 && i + k < sg.n; k++) {
-                float p = sg.p[i + k], m = sg.m[i + k], v = sg.v[i + k];
-                adam1(p, sg.g[i + k], m, v, step_size, b1, b2, inv_bc2_sqrt, eps);
-                sg.p[i + k] = p; sg.m[i + k] = m; sg.v[i + k] = v;
-            }
+        for (int k = 0; k < 4 && i + k < sg.n; k++) {
+            float p = sg.p[i + k], m = sg.m[i + k], v = sg.v[i + k];
+            adam1(p, sg.g[i + k], m, v, step_size, b1, b2, inv_bc2_sqrt, eps);
+            sg.p[i + k] = p; sg.m[i + k] = m; sg.v[i + k] = v;
         }
     }
 }
