@@ -151,6 +151,11 @@ int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits
  * (one histogram kernel for all passes, one chained-look-back kernel per pass), 2 = onesweep
  * up to 4 M keys, classic above (the default; see binning.hip for the measurements). */
 int mi3dgs_debug_set_sort_mode(int mode);
+/* The chained kernels (onesweep radix pass, device-wide scan, fused tile emit) wait on one another
+ * with BOUNDED spins; a wait that runs out sets a bit in one device word instead of hanging the
+ * GPU, and the results of that call are then wrong.  This reads (and optionally clears) the word;
+ * it synchronises, so call it where the host waits anyway.  0 = every chain resolved. */
+int mi3dgs_async_errors(uint32_t* out, int reset);
 size_t mi3dgs_scan_workspace_bytes(long long n);
 int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long long n,
                               uint32_t* total_dev /* nullable */, void* workspace,

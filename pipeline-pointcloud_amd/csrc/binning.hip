@@ -56,6 +56,17 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* to
 
 constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 24;
 
+// One device word collects the "a bounded spin ran out" bits of every chained kernel (bit 0: onesweep
+// radix pass, bit 1: chained scan / fused tile emit).  It stays set until read: mi3dgs_async_errors().
+__device__ uint32_t g_async_err = 0;
+uint32_t* async_err_ptr() {
+    static thread_local uint32_t* p[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!p[dev] && hipGetSymbolAddress((void**)&p[dev], HIP_SYMBOL(g_async_err)) != hipSuccess) p[dev] = nullptr;
+    return p[dev];
+}
+
 // ---- single-value decoupled look-back (chained scan) (used by the device-wide scan and by the fused count+emit kernel).  One
 // 64-bit word per block {flag:2 (bits 32..33) | value:32}: flag 1 = the block's own total,
 // 2 = inclusive prefix; zero (the memset state) = not there yet.  Block ids are handed out by an
@@ -177,7 +188,7 @@ int scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* 
     uint32_t nb = mi_div_up(n, SCAN_TILE);
     MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)2 * nb + 2) * sizeof(uint32_t), st));
     MI_LAUNCH(tag, scan_chained_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, out,
-              reinterpret_cast<unsigned long long*>(tmp), tmp + 2 * (size_t)nb, tmp + 2 * (size_t)nb + 1, total_out);
+              reinterpret_cast<unsigned long long*>(tmp), tmp + 2 * (size_t)nb, async_err_ptr(), total_out);
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -515,7 +526,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         // layout: ghist[4][256] | counters[8] err[1] pad[7] | status[B][256] u64
         uint32_t* ghist = tmp;
         uint32_t* counters = tmp + OS_MAX_PASSES * 256;
-        uint32_t* err = counters + 8;
+        uint32_t* err = async_err_ptr();
         unsigned long long* status = reinterpret_cast<unsigned long long*>(tmp + OS_MAX_PASSES * 256 + 16);
         // one clear per sort call: histograms, counters, and the status table (epochs 1..passes)
         MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B) * sizeof(uint32_t), st));
@@ -1071,7 +1082,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     uint32_t nblocks = (uint32_t)mi_div_up(CN, 256);
     unsigned long long* status = reinterpret_cast<unsigned long long*>(ws.cum);
     uint32_t* counter = ws.cum + 2 * (size_t)nblocks;
-    uint32_t* err = counter + 1;
+    uint32_t* err = async_err_ptr();
     MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 2) * sizeof(uint32_t), st));
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
@@ -1124,6 +1135,19 @@ extern "C" int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long
 }
 
 // A/B switch for benchmarking and tests: 0 = classic multi-kernel passes, 1 = onesweep (default).
+// Bits set by chained kernels whose bounded waits ran out (0 = all chains resolved).  Synchronises
+// with the device; `reset` clears the word.
+extern "C" int mi3dgs_async_errors(uint32_t* out, int reset) {
+    uint32_t v = 0;
+    MI_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_async_err), sizeof(v)));
+    if (out) *out = v;
+    if (reset && v) {
+        uint32_t z = 0;
+        MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_async_err), &z, sizeof(z)));
+    }
+    return 0;
+}
+
 extern "C" int mi3dgs_debug_set_sort_mode(int mode) {
     g_sort_mode = (mode < 0 || mode > 2) ? 2 : mode;
     return 0;

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "mi3dgs_sort_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_debug_set_sort_mode": (_i, [_i]),
+    "mi3dgs_async_errors": (_i, [C.POINTER(_u32), _i]),
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_scan_exclusive_u32": (_i, [_f, _f, _ll, _f, _f, _sz, _f]),
     "mi3dgs_rasterize_fwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
@@ -112,6 +113,13 @@ def profile_read() -> dict:
         tag, cnt, ms = line.rsplit(" ", 2)
         out[tag] = (int(cnt), float(ms))
     return out
+
+
+def async_errors(reset: bool = True) -> int:
+    """Bits left by chained kernels whose bounded waits ran out (0 = fine).  Synchronises."""
+    v = _u32(0)
+    check(lib().mi3dgs_async_errors(C.byref(v), int(reset)))
+    return int(v.value)
 
 
 # Optional stage hook (used by bench.py to bracket each C-ABI call with HIP events on the

@@ -399,6 +399,9 @@ class Trainer:
     def refine(self, do_grow: bool = True) -> Dict[str, int]:
         """One densify+prune pass; returns counts.  One host sync (the new Gaussian count)."""
         c, m = self.cfg, self.model
+        bad = ops._lib.async_errors()                # the host waits here anyway: did every chained kernel resolve?
+        if bad:
+            raise ops._lib.Mi3dgsError(f"a chained kernel gave up waiting (bits {bad:#x}); results since the last check are invalid")
         n = m.n
         st = ops._stream(self.device)
         flags, counts, offs = self.flags_buf[:n], self.count_buf[:n], self.offs_buf[:n]

@@ -564,3 +564,16 @@ def test_placement_tuning_is_a_no_op_on_the_model(dev):
         runs.append((losses, tr.model.p("means").clone(), tr.stats["count"].clone()))
     assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and torch.allclose(runs[0][1], runs[1][1], atol=1e-6)
     assert torch.equal(runs[0][2], runs[1][2])
+
+
+def test_no_chained_kernel_gave_up_waiting(dev):
+    """The device-wide scan, the onesweep radix passes and the fused tile emit wait on one another with
+    bounded spins; a wait that runs out leaves a bit in a sticky device word (and Trainer.refine raises on
+    it).  After everything above ran in this process the word must be clean."""
+    from mi3dgs import _lib
+    ops = _ops()
+    keys = torch.randint(0, 2 ** 31 - 1, (3_000_000,), device=dev, dtype=torch.int32)
+    vals = torch.arange(3_000_000, device=dev, dtype=torch.int32)
+    ops.sort_pairs_u32(keys, vals, 32)
+    assert bool((keys[1:] >= keys[:-1]).all())
+    assert _lib.async_errors(reset=False) == 0
