@@ -884,26 +884,40 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
     }
 }
 
-// offsets[t] = first sorted position whose key >= t   (t in [0, n_tiles_total))
+// offsets[t] = first sorted position whose key >= t   (t in [0, n_tiles_total)).  Four keys per thread
+// (one 16-byte load plus the key before them); a boundary between two different keys writes the
+// offsets of every tile id in between.
 __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ keys,
                                                            const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                            uint32_t n_tiles_total, int32_t* __restrict__ offsets) {
     uint32_t n = live_count(n_ptr, cap);
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (n == 0) {
-        if (i < n_tiles_total) offsets[i] = 0;
+        for (uint32_t t = i0; t < i0 + 4 && t < n_tiles_total; t++) offsets[t] = 0;
         return;
     }
-    if (i >= n) return;
-    uint32_t k = keys[i];
-    if (i == 0) {
-        for (uint32_t t = 0; t <= k; t++) offsets[t] = 0;
+    if (i0 >= n) return;
+    uint32_t k[4];
+    if (i0 + 4 <= n) {
+        uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
+        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
     } else {
-        uint32_t kp = keys[i - 1];
-        for (uint32_t t = kp + 1; t <= k; t++) offsets[t] = (int32_t)i;
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? keys[i0 + j] : 0u;
     }
-    if (i == n - 1)
-        for (uint32_t t = k + 1; t < n_tiles_total; t++) offsets[t] = (int32_t)n;
+    uint32_t prev = i0 == 0 ? 0u : keys[i0 - 1];
+    if (i0 == 0)
+        for (uint32_t t = 0; t <= k[0]; t++) offsets[t] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t i = i0 + j;
+        if (i >= n) break;
+        if (i > 0)
+            for (uint32_t t = prev + 1; t <= k[j]; t++) offsets[t] = (int32_t)i;
+        prev = k[j];
+        if (i == n - 1)
+            for (uint32_t t = k[j] + 1; t < n_tiles_total; t++) offsets[t] = (int32_t)n;
+    }
 }
 
 __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restrict__ keys,
@@ -1003,7 +1017,7 @@ static int bin_sort_and_offsets(const BinWs& ws, uint32_t* tk, uint32_t* fi, con
         MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
     }
     uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
-    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(g, 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
+    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(mi_div_up(g, 4), 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
                        cap, n_tiles_total, isect_offsets);
     if (isect_ids_opt)
         MI_LAUNCH("isect_ids", isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
