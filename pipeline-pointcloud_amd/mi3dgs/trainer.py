@@ -283,7 +283,8 @@ class Trainer:
 
     # -- HBM placement of the parameter / moment arrays ------------------------------------
     @torch.no_grad()
-    def tune_placement(self, sweeps: int = 24, min_gain: float = 0.003, budget_s: float = 3.0, log=None) -> Dict[str, float]:
+    def tune_placement(self, sweeps: int = 24, min_gain: float = 0.003, budget_s: float = 3.0, min_gaussians: int = 200_000,
+                       log=None) -> Dict[str, float]:
         """The fused backward+Adam kernel streams 18 arrays (6 groups x parameter / exp_avg /
         exp_avg_sq) at once, and its speed depends on which physical pages each of them got: 576 to
         677 us on identical code and addresses ("placement").  This walks the arrays of
@@ -292,7 +293,9 @@ class Trainer:
         gradients, zero moments, zero learning rates), so it must be called before the first step.
         Costs a few hundred milliseconds and, transiently, a few GB."""
         c, m = self.cfg, self.model
-        if not (c.fuse_adam and self._can_fuse_adam()) or m.n == 0 or self.step_count != 0:
+        if not (c.fuse_adam and self._can_fuse_adam()) or self.step_count != 0:
+            return {}
+        if m.n < min_gaussians:                  # the kernel is launch-bound down here; nothing to gain
             return {}
         n = m.n
         viewmat, K = self.viewmats[:1], self.Ks[:1]
@@ -326,6 +329,18 @@ class Trainer:
         rng = random.Random(1234)
         t_start = time.time()
         report, graveyard = {}, []
+        # losers are held (so that the next candidate gets other pages) up to a memory budget: a quarter of
+        # what is free now, at most 16 GiB; beyond it the oldest are released
+        free_now = torch.cuda.mem_get_info(self.device)[0]
+        hold_budget = int(min(16 << 30, free_now // 4))
+
+        def bury(t):
+            graveyard.append(t)
+            held = sum(x.numel() * x.element_size() for x in graveyard)
+            while held > hold_budget and len(graveyard) > 1:
+                x = graveyard.pop(0)
+                held -= x.numel() * x.element_size()
+
         shared = [(self.__dict__, k) for k in ("splats", "v_splats", "radii")] + [(self.stats, k) for k in self.stats]
         spare = [bk for i, bk in enumerate(m.banks) if i != m.cur]
         for bk in spare:                          # the spare bank has to hold real parameters while it is timed
@@ -346,7 +361,9 @@ class Trainer:
                     old = holder[key]
                     # a throw-away block of random size first, so that the candidate does not simply land
                     # where the previous loser was (or right behind the last allocation)
-                    graveyard.append(torch.empty(rng.choice((1, 3, 7, 13, 29)) << 20, dtype=torch.uint8, device=self.device))
+                    bury(torch.empty(rng.choice((1, 3, 7, 13, 29)) << 20, dtype=torch.uint8, device=self.device))
+                    if old.numel() * old.element_size() * 2 > hold_budget:
+                        continue                             # too large to keep a second copy around
                     new = torch.empty_like(old)              # fresh pages: `old` is still held
                     new.copy_(old)
                     holder[key] = new
@@ -354,10 +371,10 @@ class Trainer:
                     if t < best[b] * (1.0 - min_gain):
                         best[b] = t
                         improved = True
-                        graveyard.append(old)
+                        bury(old)
                     else:
                         holder[key] = old
-                        graveyard.append(new)
+                        bury(new)
                 if b == m.cur:                     # the shared arrays moved: the other banks' times are stale
                     for ob, obank in enumerate(m.banks):
                         if ob != b:
