@@ -141,7 +141,8 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int = 100, save_steps=(),
-                 on_save=None, strategy: str = "default", cap_max: int = 1_000_000) -> Tuple[object, object, Dict]:
+                 on_save=None, strategy: str = "default", cap_max: int = 1_000_000, init_opacity: float = 0.1,
+                 init_scale: float = 1.0) -> Tuple[object, object, Dict]:
     """Loads the dataset, trains, evaluates.  Returns (trainer, dataset, stats)."""
     from . import dataset as ds_mod
     from . import parallel
@@ -157,7 +158,7 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
         cfg = cfg(ds)
     n_pts = ds.points.shape[0]
     say(f"dataset: {len(ds.train_idx)} train / {len(ds.eval_idx)} eval images {ds.width}x{ds.height}, {n_pts} SfM points")
-    params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb)
+    params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb, init_opacity=init_opacity, init_scale=init_scale)
     imgs = ds.load_images(ds.train_idx, dev, as_u8=True)       # device image cache (uint8)
     vm, ks = ds.viewmats[ds.train_idx].to(dev), ds.Ks[ds.train_idx].to(dev)
     if strategy == "mcmc":
@@ -295,7 +296,10 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
     save_steps = {max(1, int(s * a["steps_scaler"])) for s in (7000, 30000)}
     tr, ds, stats = run_training(a["data_dir"], a["data_factor"], cfg, ctx=ctx if world > 1 else None,
                                  save_steps=save_steps, on_save=save, strategy=a["strategy"],
-                                 cap_max=min(a["max_gaussians"], 1_000_000) if a["strategy"] == "mcmc" else a["max_gaussians"])
+                                 cap_max=min(a["max_gaussians"], 1_000_000) if a["strategy"] == "mcmc" else a["max_gaussians"],
+                                 # gsplat's `mcmc` preset: init_opa 0.5, init_scale 0.1 [UPSTREAM-UNVERIFIED]
+                                 init_opacity=0.5 if a["strategy"] == "mcmc" else 0.1,
+                                 init_scale=0.1 if a["strategy"] == "mcmc" else 1.0)
     save(tr, ds, cfg.max_steps - 1)            # every rank holds the full (replicated) model
     if rank == 0:
         os.makedirs(os.path.join(a["result_dir"], "stats"), exist_ok=True)
