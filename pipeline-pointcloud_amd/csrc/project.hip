@@ -224,8 +224,12 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float4* rec = reinterpret_cast<float4*>(splats + idx_c * SPLAT_STRIDE);
     int2* rad = reinterpret_cast<int2*>(radii + idx_c * 2);
 
-    Cam cam = load_cam(viewmats, Ks, c);
+    // one camera: a compile-time index, so the matrices arrive through scalar loads instead of a
+    // per-lane gather that everything else would have to wait for
+    Cam cam = (C == 1) ? load_cam(viewmats, Ks, 0) : load_cam(viewmats, Ks, c);
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    // the opacity travels with the means (it used to be a separate round trip after the projection)
+    const float opa_raw = opacities != nullptr ? opacities[n] : 1.f;
     float zc = cam.R[6] * mean[0] + cam.R[7] * mean[1] + cam.R[8] * mean[2] + cam.t[2];
     bool ok = live && (zc >= near_plane) && (zc <= far_plane);
     Proj P;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         ok = P.det > 0.f;
         float extend = 3.33f;
         if (ok && opacities != nullptr) {
-            opa = opacities[n];
+            opa = opa_raw;
             if (flags & MI_FLAG_LOGIT_OPAC) opa = sigmoidf(opa);
             if (flags & MI_FLAG_ANTIALIASED) opa *= P.comp;
             if (opa < ALPHA_THRESHOLD) ok = false;
@@ -259,7 +263,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             if (P.m2x + rx <= 0.f || P.m2x - rx >= (float)W || P.m2y + ry <= 0.f || P.m2y - ry >= (float)H) ok = false;
         }
     }
-    // ---- stage this wave's shN slice (wave-uniform decision)
+    // ---- stage this wave's shN slice (wave-uniform decision); the DC coefficients are requested in the
+    // same breath (they used to be one more round trip after the slice)
+    float c0[3] = {0.f, 0.f, 0.f};
+    if (color_mode == 0 && ok) { c0[0] = sh0[3 * (long long)n]; c0[1] = sh0[3 * (long long)n + 1]; c0[2] = sh0[3 * (long long)n + 2]; }
     bool staged = false;
     if (color_mode == 0 && sh_degree >= 2) {
         long long idx0 = idx - lane;                                  // first record of the wave
@@ -300,7 +307,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
         float b[16];
         sh_basis(sh_degree, dx * inv, dy * inv, dz * inv, b);
-        const float* c0 = sh0 + 3 * (long long)n;
         rgb[0] = b[0] * c0[0]; rgb[1] = b[0] * c0[1]; rgb[2] = b[0] * c0[2];
         int nb = (sh_degree + 1) * (sh_degree + 1);
         if (staged) {
