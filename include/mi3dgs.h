@@ -42,6 +42,8 @@ extern "C" {
 #define MI3DGS_FLAG_LOG_SCALES 1   /* scales are log-space parameters; exp() fused */
 #define MI3DGS_FLAG_LOGIT_OPAC 2   /* opacities are logits; sigmoid() fused */
 #define MI3DGS_FLAG_ANTIALIASED 4  /* rasterize_mode "antialiased": opacity *= compensation */
+#define MI3DGS_FLAG_PROBE 16       /* mi3dgs_project_bwd_adam: identical code under a kernel name of its
+                                    * own, for the timed no-op launches of a placement search */
 
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */

@@ -39,6 +39,7 @@
 #define MI_FLAG_LOG_SCALES 1      // scales are log-space parameters (exp applied in-kernel)
 #define MI_FLAG_LOGIT_OPAC 2      // opacities are logits (sigmoid applied in-kernel)
 #define MI_FLAG_ANTIALIASED 4     // rasterize_mode == "antialiased": opacity *= compensation
+#define MI_FLAG_PROBE 16          // project_bwd_adam: same code under another kernel name (placement search)
 
 #define ALPHA_THRESHOLD (1.0f / 255.0f)
 #define MAX_ALPHA 0.999f

@@ -21,6 +21,7 @@ GRAD_STRIDE = 16
 FLAG_LOG_SCALES = 1
 FLAG_LOGIT_OPAC = 2
 FLAG_ANTIALIASED = 4
+FLAG_PROBE = 16
 COLOR_SH, COLOR_PER_GAUSSIAN, COLOR_PER_CAMERA = 0, 1, 2
 
 

@@ -309,7 +309,7 @@ class Trainer:
             ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
                                  [bank[g]["v"] for g in GROUPS], (0.0,) * 6, 1, viewmat, K, self.W, self.H,
                                  self.radii[:, :n], self.splats[:, :n], self.v_splats[:, :n], n=n, sh_degree=sd,
-                                 flags=self._flags(), beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                                 flags=self._flags() | ops.FLAG_PROBE, beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
                                  stats={k: v[:n] for k, v in self.stats.items()} if track else None,
                                  stat_use_abs=c.absgrad)
 
