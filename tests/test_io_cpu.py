@@ -250,3 +250,49 @@ def test_ns_export_shim_writes_splat_ply(tmp_path):
     assert cli.main_ns_export(["gaussian-splat", "--load-config", str(cfgp), "--output-dir", str(tmp_path / "exports")]) == 0
     R = io_ply.read_ply(str(tmp_path / "exports" / "splat.ply"))
     assert torch.equal(R["means"], S["means"])
+
+
+def test_colmap_to_json_shim_writes_transforms_and_point_cloud(tmp_path, capsys):
+    """`training/colmap_to_nerfstudio_cam.py -d D` (reference main.py:1220-1226): transforms.json in nerfstudio's
+    conventions and the ASCII point cloud beside the sparse model."""
+    import json
+    from mi3dgs import colmap_json
+    rng = np.random.default_rng(4)
+    cams = [io_colmap.Camera(1, "OPENCV", 640, 480, np.array([500.0, 505.0, 321.0, 239.0, -0.1, 0.02, 0.001, -0.002]))]
+    ims = []
+    for i in range(5):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        ims.append(io_colmap.Image(i + 1, q, rng.normal(size=3), 1, f"frame_{i:03d}.jpg"))
+    xyz = rng.normal(size=(40, 3)) * 3.0
+    rgb = rng.integers(0, 256, (40, 3)).astype(np.uint8)
+    io_colmap.write_model(str(tmp_path / "sparse" / "0"), cams, ims, xyz, rgb)
+    assert colmap_json.main(["-d", str(tmp_path)]) == 0
+    assert "creating transforms.json file" in capsys.readouterr().out
+    T = json.load(open(tmp_path / "transforms.json"))
+    assert (T["w"], T["h"], T["camera_model"]) == (640, 480, "OPENCV")
+    assert [T[k] for k in ("fl_x", "fl_y", "cx", "cy", "k1", "k2", "p1", "p2")] == [500.0, 505.0, 321.0, 239.0, -0.1, 0.02, 0.001, -0.002]
+    assert T["ply_file_path"] == f"{tmp_path}/sparse/0/sparse.ply" and len(T["frames"]) == 5
+    A = np.array(T["applied_transform"])
+    assert A.tolist() == [[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0]]
+    for fr, im in zip(T["frames"], ims):
+        assert fr["file_path"] == f"images/{im.name}" and fr["colmap_im_id"] == im.id
+        c2w = np.array(fr["transform_matrix"])
+        assert np.allclose(c2w[3], [0, 0, 0, 1])
+        # a world point seen through the json pose (OpenGL axes, transformed world) = the COLMAP camera point with y, z negated
+        X = rng.normal(size=3)
+        x_cv = (im.world_to_camera() @ np.append(X, 1.0))[:3]
+        x_gl = (np.linalg.inv(c2w) @ np.append(A[:, :3] @ X + A[:, 3], 1.0))[:3]
+        assert np.allclose(x_gl, x_cv * [1, -1, -1], atol=1e-9)
+    lines = open(tmp_path / "sparse" / "0" / "sparse.ply").read().splitlines()
+    assert lines[:3] == ["ply", "format ascii 1.0", "element vertex 40"] and lines[9] == "end_header" and len(lines) == 50
+    row = lines[10].split()
+    assert np.allclose([float(v) for v in row[:3]], A[:, :3] @ xyz[0], atol=1e-5) and [int(v) for v in row[3:]] == rgb[0].tolist()
+    # the reference script's soft failures: messages, exit code 0
+    assert colmap_json.main(["-d", str(tmp_path / "nope")]) == 0 and "doesn't exist" in capsys.readouterr().out
+    os.makedirs(tmp_path / "empty")
+    assert colmap_json.main(["-d", str(tmp_path / "empty")]) == 0 and "Sparse path does not currently exist" in capsys.readouterr().out
+    # two cameras are refused the way nerfstudio refuses them
+    io_colmap.write_model(str(tmp_path / "two" / "sparse" / "0"), cams + [io_colmap.Camera(2, "PINHOLE", 640, 480, np.array([500.0, 500, 320, 240]))],
+                          ims, xyz, rgb)
+    with pytest.raises(RuntimeError, match="Only single camera"):
+        colmap_json.main(["-d", str(tmp_path / "two")])
