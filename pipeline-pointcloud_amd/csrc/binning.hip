@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t chain_lookback(unsigned long long* status, u
                 }
             }
             uint32_t val = (uint32_t)w;
-            unsigned long long pm = __ballot(((w >> 32) & 3ull) == 2ull);
+            unsigned long long pm = wave_ballot(((w >> 32) & 3ull) == 2ull);
             if (pm) {
                 int f = __ffsll((long long)pm) - 1;                  // nearest predecessor holding a prefix
                 excl += wave_sum_u32(lane <= f ? val : 0u);
@@ -285,11 +285,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
         uint32_t d = (key[r] >> shift) & mask;
-        unsigned long long peers = __ballot(valid);
+        unsigned long long peers = wave_ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             bool bit = (d >> b) & 1u;
-            unsigned long long m = __ballot(bit);
+            unsigned long long m = wave_ballot(bit);
             peers &= bit ? m : ~m;
         }
         uint32_t rank = __popcll(peers & lt_mask);
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         bool valid = idx < n;
         uint32_t k = key[r];
         uint32_t d = (k >> shift) & mask;
-        unsigned long long peers = __ballot(valid);
+        unsigned long long peers = wave_ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             bool bit = (d >> b) & 1u;
-            unsigned long long m = __ballot(bit);
+            unsigned long long m = wave_ballot(bit);
             peers &= bit ? m : ~m;
         }
         uint32_t rank = __popcll(peers & lt_mask);

@@ -181,4 +181,9 @@ __device__ __forceinline__ void mi_adam1(float& p, float g, float& m, float& v, 
     p -= step_size * m / denom;
 }
 
+// 64-bit lane mask of a predicate.  HIP's __ballot(int) compares an INTEGER against zero, so a bool goes
+// bool -> v_cndmask(0,1) -> v_cmp_ne_u32: two VALU instructions to rebuild a mask that already sits
+// in an SGPR pair.  The builtin takes the i1 directly (an s_and with exec, or nothing at all).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         int n0 = (int)(idx0 - (long long)(idx0 / N) * N);
         bool whole = idx0 + 63 < (long long)C * N && (idx0 / N) == ((idx0 + 63) / N);   // one camera, 64 live lanes
         const float* src = shN + 45 * (long long)n0;
-        if (whole && (((uintptr_t)src) & 15) == 0 && __ballot(ok) != 0ull) {
+        if (whole && (((uintptr_t)src) & 15) == 0 && wave_ballot(ok) != 0ull) {
             staged = true;
             const float4* s4 = reinterpret_cast<const float4*>(src);
             // loads first (index clamped, no branch), LDS stores after: with the bounds test around each
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     int2 rad = make_int2(0, 0);
     if (live) rad = *reinterpret_cast<const int2*>(radii + 2 * (long long)n);
     const bool vis = live && rad.x > 0 && rad.y > 0;
-    const bool need_coef = sh_degree >= 1 && __ballot(vis) != 0ull;
+    const bool need_coef = sh_degree >= 1 && wave_ballot(vis) != 0ull;
     // FUSE: the lane that stages float4 number i4 of the slice is also the lane that applies Adam to
     // it at the end, so the coefficients stay in 48 registers instead of being read from HBM twice
     // (the kernel sits at 3 waves per SIMD because of its LDS, which leaves 168 VGPRs).

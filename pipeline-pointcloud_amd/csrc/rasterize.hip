@@ -40,14 +40,45 @@ __device__ __forceinline__ void pixel_of_thread(int tid, int& lx, int& ly) {
     ly = ((w >> 1) << 3) + (l >> 3);
 }
 
+// Two-wide float vectors: clang lowers their +, * and fma to v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32,
+// one VALU issue for two lanes' worth of work.  Both rasterisers are 100 % VALU-issue bound
+// (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = the kernel duration), so the splats are staged in LDS as
+// PAIRS, field by field, and everything that does not depend on the transmittance chain is
+// evaluated for two splats per instruction.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr float LOG2E = 1.4426950408889634f;
+
+// LDS record of a pair of splats (k even, k+1):
+//   q0 = (x0, x1, y0, y1)            q1 = (A0', A1', B0', B1')     A' = -log2e A / 2, B' = -log2e B
+//   q2 = (C0', C1', o0, o1)          q3 = (r0, g0, r1, g1)         C' = -log2e C / 2
+//   q4 = (b0, b1)                    so that  log2(vis) = A' dx^2 + C' dy^2 + B' dx dy  directly
+struct PairLds {
+    float4 q0[BLOCK / 2], q1[BLOCK / 2], q2[BLOCK / 2], q3[BLOCK / 2];
+    float2 q4[BLOCK / 2];
+};
+
+__device__ __forceinline__ void pair_store(PairLds& L, int slot, float4 a, float4 bb, float c) {
+    // a = (x, y, conic A, conic B), bb = (conic C, opacity, r, g), c = b
+    float* q0 = reinterpret_cast<float*>(&L.q0[slot >> 1]);
+    float* q1 = reinterpret_cast<float*>(&L.q1[slot >> 1]);
+    float* q2 = reinterpret_cast<float*>(&L.q2[slot >> 1]);
+    float* q3 = reinterpret_cast<float*>(&L.q3[slot >> 1]);
+    float* q4 = reinterpret_cast<float*>(&L.q4[slot >> 1]);
+    int h = slot & 1;
+    q0[h] = a.x; q0[2 + h] = a.y;
+    q1[h] = -0.5f * LOG2E * a.z; q1[2 + h] = -LOG2E * a.w;
+    q2[h] = -0.5f * LOG2E * bb.x; q2[2 + h] = bb.y;
+    q3[2 * h] = bb.z; q3[2 * h + 1] = bb.w;
+    q4[h] = c;
+}
+
 template <bool HAS_BG>
 __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
     int32_t* __restrict__ last_ids) {
-    __shared__ float4 sA[BLOCK], sB[BLOCK];
-    __shared__ float sC[BLOCK];
+    __shared__ PairLds L;
     int t = blockIdx.x;
     int cam = t / (tw * th);
     int tile_in = t - cam * (tw * th);
@@ -56,11 +87,12 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     pixel_of_thread(threadIdx.x, lx, ly);
     int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
     bool inside = px_i < W && py_i < H;
-    float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const f2 PX = {(float)px_i + 0.5f, (float)px_i + 0.5f}, PY = {(float)py_i + 0.5f, (float)py_i + 0.5f};
     int start = tile_offsets[t];
     int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
 
-    float T = 1.f, r = 0.f, g = 0.f, b = 0.f;
+    float T = 1.f, b = 0.f;
+    f2 RG = {0.f, 0.f};
     int cur = 0;
     bool done = !inside;
     for (int bs = start; bs < end; bs += BLOCK) {
@@ -70,11 +102,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
             const float4* rec = reinterpret_cast<const float4*>(splats + (size_t)flatten_ids[idx] * SPLAT_STRIDE);
             float4 a = rec[0], bb = rec[1];
             float c = reinterpret_cast<const float*>(rec)[SP_B];
-            sA[threadIdx.x] = a; sB[threadIdx.x] = bb; sC[threadIdx.x] = c;
+            pair_store(L, (int)threadIdx.x, a, bb, c);
         } else {
             // pad the tail with zero-opacity records so the unrolled body needs no bounds test
-            sA[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f); sB[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-            sC[threadIdx.x] = 0.f;
+            pair_store(L, (int)threadIdx.x, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0.f);
         }
         __syncthreads();
         int bsz = min(BLOCK, end - bs);
@@ -83,31 +114,42 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
         // wave-uniform branches remain: "whole wave finished" per group of 4 splats and
         // "no lane of the wave is touched by this splat".
         for (int k0 = 0; k0 < bsz; k0 += 4) {
-            if (__ballot(!done) == 0ull) break;
-            // independent part first (4 records, 4 exps in flight), dependent T chain after
-            float4 bb[4];
-            float cb[4], alpha[4];
+            if (wave_ballot(!done) == 0ull) break;
+            // independent part first, two splats per instruction; the dependent T chain after
+            float alpha[4], cr[4], cg[4], cb[4];
             bool hit[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                float4 a = sA[k0 + u];
-                bb[u] = sB[k0 + u];
-                cb[u] = sC[k0 + u];
-                float dx = a.x - px, dy = a.y - py;
-                float sigma = 0.5f * (a.z * dx * dx + bb[u].x * dy * dy) + a.w * dx * dy;
-                alpha[u] = fminf(MAX_ALPHA, bb[u].y * __expf(-sigma));
-                hit[u] = sigma >= 0.f && alpha[u] >= ALPHA_THRESHOLD;
+            for (int pr = 0; pr < 2; pr++) {
+                const int j = (k0 >> 1) + pr;
+                const float4 q0 = L.q0[j], q1 = L.q1[j], q2 = L.q2[j], q3 = L.q3[j];
+                const float2 q4 = L.q4[j];
+                const f2 X = {q0.x, q0.y}, Y = {q0.z, q0.w}, A = {q1.x, q1.y}, B = {q1.z, q1.w}, C = {q2.x, q2.y},
+                         O = {q2.z, q2.w};
+                const f2 DX = X - PX, DY = Y - PY;
+                const f2 Tq = B * DY + A * DX;                  // log2(vis) = dx (A' dx + B' dy) + C' dy^2
+                f2 S = DX * Tq;
+                S = (C * DY) * DY + S;
+                const f2 E = {__builtin_amdgcn_exp2f(S.x), __builtin_amdgcn_exp2f(S.y)};
+                const f2 AL = O * E;
+                alpha[2 * pr] = fminf(MAX_ALPHA, AL.x);
+                alpha[2 * pr + 1] = fminf(MAX_ALPHA, AL.y);
+                hit[2 * pr] = S.x <= 0.f && alpha[2 * pr] >= ALPHA_THRESHOLD;          // sigma >= 0
+                hit[2 * pr + 1] = S.y <= 0.f && alpha[2 * pr + 1] >= ALPHA_THRESHOLD;
+                cr[2 * pr] = q3.x; cg[2 * pr] = q3.y; cr[2 * pr + 1] = q3.z; cg[2 * pr + 1] = q3.w;
+                cb[2 * pr] = q4.x; cb[2 * pr + 1] = q4.y;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 bool ok = !done && hit[u];
-                if (__ballot(ok) == 0ull) continue;
+                if (wave_ballot(ok) == 0ull) continue;
                 float nT = T * (1.f - alpha[u]);
                 bool stop = ok && nT <= T_STOP;
                 done = done || stop;
                 ok = ok && !stop;
                 float wgt = ok ? alpha[u] * T : 0.f;
-                r += bb[u].z * wgt; g += bb[u].w * wgt; b += cb[u] * wgt;
+                const f2 Wg = {wgt, wgt}, Cc = {cr[u], cg[u]};
+                RG = Cc * Wg + RG;
+                b += cb[u] * wgt;
                 cur = ok ? bs + k0 + u : cur;
                 T = ok ? nT : T;
             }
@@ -115,6 +157,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     }
     if (inside) {
         size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        float r = RG.x, g = RG.y;
         if (HAS_BG) {
             const float* bg = backgrounds + 3 * cam;
             r += T * bg[0]; g += T * bg[1]; b += T * bg[2];
@@ -208,14 +251,14 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
             bool valid = (sidx <= bin_final) && !(sigma < 0.f || alpha < ALPHA_THRESHOLD);
 #ifdef MI_RASTER_STATS
             {
-                unsigned long long bm = __ballot(valid);
+                unsigned long long bm = wave_ballot(valid);
                 if (lane == 0) {
                     atomicAdd(&g_raster_stats[0], 1ull);
                     if (bm) { atomicAdd(&g_raster_stats[1], 1ull); atomicAdd(&g_raster_stats[2], (unsigned long long)__popcll(bm)); }
                 }
             }
 #endif
-            if (__ballot(valid) == 0ull) continue;
+            if (wave_ballot(valid) == 0ull) continue;
             // Branch-free live part: a dead lane runs it with alpha = 0 (ra = 1, T and buf
             // unchanged bit for bit, every partial 0), so no exec-mask region is needed.
             float a_eff = valid ? alpha : 0.f;

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(uint32_t n, const float4
         }
     }
     // wave-aggregated append of the open queries
-    unsigned long long open = __ballot(!done);
+    unsigned long long open = wave_ballot(!done);
     if (open) {
         uint32_t base = 0;
         int leader = __ffsll((long long)open) - 1;
