@@ -181,7 +181,20 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     rank = ctx.rank if ctx is not None else 0
     t_train = time.time()
     t_last, s_last = t_train, 0
+    from . import _lib
+    prof = os.environ.get("MI3DGS_PROFILE_STEPS")          # "a:b": per-kernel table of steps [a, b) on rank 0
+    prof_a, prof_b = (int(x) for x in prof.split(":")) if prof else (-1, -1)
     for step in range(cfg.max_steps):
+        if rank == 0 and step == prof_a:
+            _lib.profile_enable(True)
+        if rank == 0 and step == prof_b:
+            torch.cuda.synchronize()
+            table = _lib.profile_read()
+            _lib.profile_enable(False)
+            tot = sum(v[1] for v in table.values())
+            say(f"profile of steps {prof_a}..{prof_b}: {tot / (prof_b - prof_a):.3f} ms of kernels per step")
+            for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:14]:
+                say(f"  {k:24s} {v[1] / (prof_b - prof_a):7.3f} ms/step  {v[0] / (prof_b - prof_a):5.1f} launches  {1e3 * v[1] / max(v[0], 1):8.1f} us each")
         slot = step * world + rank
         if slot % V == 0 and slot > 0:
             order = torch.randperm(V, generator=g).tolist()
@@ -220,7 +233,7 @@ def world_frame_splats(tr, ds) -> Dict[str, torch.Tensor]:
 
 # ------------------------------------------------------------------------ entry points
 def main_ns_train(argv: Optional[List[str]] = None) -> int:
-    from . import io_ply
+    from . import _lib, io_ply
     a = parse_ns_train(sys.argv[1:] if argv is None else argv)
     if a["model"] not in SPLATFACTO_MODELS:
         raise SystemExit(f"ns-train (mi3dgs): model {a['model']!r} is not implemented; supported: {SPLATFACTO_MODELS}")

@@ -440,6 +440,43 @@ def test_tight_binning_is_conservative_and_renders_bit_identical(dev, seed, big)
     print(f"intersections: box {n_box}, tight {n_tight} ({100.0 * n_tight / n_box:.0f} %), exact {need.numel()}")
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_big_splats_take_the_wave_per_splat_emit_path(dev, fused):
+    """Splats tens of tile rows tall overflow the block's row table (2 048 rows per 256 splats) and are emitted by
+    the wave-per-splat path of tile_emit: same pair set rules as everywhere else, renders identical to box binning."""
+    ops = _ops()
+    W, H = 352, 288                                           # 22 x 18 tiles
+    sc = small_scene(n=700, seed=61, big=True, n_views=1, width=W, height=H, fx=200.0)
+    sc.params["scales"] += 1.6                                # radii of a hundred pixels and more
+    sc.params["scales"][:400, 0] += 1.0
+    g = sc.to(dev)
+    radii, splats = ops.project_fwd(g.params["means"], g.params["quats"], g.params["scales"], g.params["opacities"],
+                                    g.viewmats, g.Ks, W, H, sh0=g.params["sh0"], shN=g.params["shN"], sh_degree=3, flags=3)
+    rows = ((radii[0, :, 1].float() * 2 + 15) / 16).clamp(max=18)
+    assert float(rows[radii[0, :, 1] > 0].mean()) > 10.0       # way past 8 rows per splat: the table overflows
+    box = ops.bin_tiles(radii, splats, W, H, 16, want_tiles_per_gauss=True)
+    I_box = int(box["n_isect"].item())
+    tight = ops.bin_tiles(radii, splats, W, H, 16, want_tiles_per_gauss=True, tight=True,
+                          max_isect=I_box if fused else None, fused=fused)
+    I = int(tight["n_isect"].item())
+    assert 0 < I < I_box and I == int(tight["tiles_per_gauss"].sum())
+    N = 700
+    sp = splats.cpu()
+    need = O.contributing_pairs(sp[..., 0:2], sp[..., 2:5], sp[..., 5], radii.cpu(), W, H)
+    ct = torch.sort(tight["tile_keys"][:I].long().cpu() * N + tight["flatten_ids"][:I].long().cpu() % N).values
+    cb = torch.sort(box["tile_keys"].long().cpu() * N + box["flatten_ids"].long().cpu() % N).values
+    assert torch.unique(ct).numel() == ct.numel(), "a (tile, splat) pair was emitted twice"
+    assert torch.isin(need, ct).all() and torch.isin(ct, cb).all()
+    tk = tight["tile_keys"][:I].long().cpu()
+    assert (tk[1:] >= tk[:-1]).all()
+    dep = sp[..., 9].flatten()[tight["flatten_ids"][:I].long().cpu()]
+    same = tk[1:] == tk[:-1]
+    assert (dep[1:][same] >= dep[:-1][same]).all()
+    r0, a0, _ = [t.clone() for t in ops.rasterize_fwd(splats, box, W, H, 16)]
+    r1, a1, _ = ops.rasterize_fwd(splats, tight, W, H, 16)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+
+
 # --------------------------------------------------------- Adam fused into the backward
 @pytest.mark.parametrize("n,scale_reg", [(700, False), (333, True), (64, True)])
 def test_fused_adam_backward_equals_separate_kernels(dev, n, scale_reg):
