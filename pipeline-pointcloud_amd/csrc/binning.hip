@@ -775,6 +775,7 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
     __shared__ uint32_t s_id[256], s_key0[256];
     __shared__ int s_w[256];
     __shared__ uint8_t s_slow[256];
+    __shared__ unsigned long long s_slowmask[4];
     __shared__ SpanGeom s_geo[TIGHT ? 256 : 1];
     __shared__ RowTable T[1];
     __shared__ uint32_t s_blk, s_base, s_scan4[4];
@@ -812,6 +813,8 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         bool slow;
         my_n = build_row_table(T[0], s_geo, vis, tile_size, H, slow);   // same arithmetic as tile_count_kernel<true>
         s_slow[threadIdx.x] = slow ? 1 : 0;
+        unsigned long long sm = wave_ballot(slow);
+        if (lane_id() == 0) s_slowmask[threadIdx.x >> 6] = sm;
     }
     if (CHAINED) {
         uint32_t total;
@@ -883,8 +886,11 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         __shared__ uint32_t s_wcum[4][65];
         __shared__ uint16_t s_wtx0[4][64];
         const int wv = threadIdx.x >> 6, lane = lane_id();
-        for (int g = wv; g < 256; g += 4) {
-            if (!s_slow[g]) continue;                                      // wave-uniform
+        int taken = 0;                                                     // the slow splats go round the 4 waves
+        for (int jm = 0; jm < 4; jm++)
+        for (unsigned long long sm = s_slowmask[jm]; sm; sm &= sm - 1ull) {
+            const int g = 64 * jm + (int)__builtin_ctzll(sm);
+            if ((taken++ & 3) != wv) continue;                             // wave-uniform
             const SpanGeom geo = s_geo[g];
             const int rows = geo.y1 - geo.y0;
             uint32_t outbase = s_cum[g];
