@@ -632,6 +632,8 @@ __device__ __attribute__((noinline)) void row_span(const SpanGeom& g, int ty, in
 // key: 656 us instead of 87 for tile_emit.)  Splats whose rows do not fit the pool (more than
 // ROW_POOL rows in one block: rare, huge splats) are flagged `slow` and use the row walk.
 constexpr int ROW_POOL = 2048;
+constexpr int SLOW_BLOCKS = 2048;   // x 4 waves striding over the list of big splats
+constexpr int SLOW_WORDS = 16;      // one 64-byte list entry per big splat: SpanGeom (11 words), id, first output position, key base
 
 struct RowTable {
     uint32_t row_base[257];        // exclusive scan of rows per splat, [256] = total
@@ -770,12 +772,12 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
                                                         uint32_t* __restrict__ flat_ids,
                                                         unsigned long long* status, uint32_t* chain_counter,
                                                         uint32_t* chain_err, uint32_t* __restrict__ n_isect_out,
-                                                        uint32_t* __restrict__ tiles_out) {
+                                                        uint32_t* __restrict__ tiles_out, uint32_t* __restrict__ slow_list,
+                                                        uint32_t* slow_count) {
     __shared__ uint32_t s_cum[257];
     __shared__ uint32_t s_id[256], s_key0[256];
     __shared__ int s_w[256];
     __shared__ uint8_t s_slow[256];
-    __shared__ unsigned long long s_slowmask[4];
     __shared__ SpanGeom s_geo[TIGHT ? 256 : 1];
     __shared__ RowTable T[1];
     __shared__ uint32_t s_blk, s_base, s_scan4[4];
@@ -813,8 +815,6 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         bool slow;
         my_n = build_row_table(T[0], s_geo, vis, tile_size, H, slow);   // same arithmetic as tile_count_kernel<true>
         s_slow[threadIdx.x] = slow ? 1 : 0;
-        unsigned long long sm = wave_ballot(slow);
-        if (lane_id() == 0) s_slowmask[threadIdx.x >> 6] = sm;
     }
     if (CHAINED) {
         uint32_t total;
@@ -829,6 +829,28 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         __syncthreads();
         my_cum = s_base + local;
         if (tiles_out && i < CN) tiles_out[idx] = my_n;
+    }
+    if (TIGHT) {
+        // Splats with more tile rows than the block's row table holds (big splats: few Gaussians at a
+        // high resolution, early training) go on a list and are emitted by tile_emit_slow_kernel, one
+        // wave per splat across the whole GPU.  The entry carries the span geometry itself, so that the
+        // rows come out exactly as they were counted here.
+        bool slow_me = s_slow[threadIdx.x] != 0;
+        unsigned long long sm = wave_ballot(slow_me);
+        if (sm) {
+            uint32_t basepos = 0;
+            int leader = (int)__builtin_ctzll(sm);
+            if ((int)lane_id() == leader) basepos = atomicAdd(slow_count, (uint32_t)__popcll(sm));
+            basepos = __shfl(basepos, leader, 64);
+            if (slow_me) {
+                uint32_t* e = slow_list + (size_t)(basepos + (uint32_t)__popcll(sm & ((1ull << lane_id()) - 1ull))) * SLOW_WORDS;
+                const SpanGeom gg = s_geo[threadIdx.x];
+                e[0] = __float_as_uint(gg.mx); e[1] = __float_as_uint(gg.my); e[2] = __float_as_uint(gg.A);
+                e[3] = __float_as_uint(gg.B); e[4] = __float_as_uint(gg.C); e[5] = __float_as_uint(gg.tau2);
+                e[6] = (uint32_t)gg.x0; e[7] = (uint32_t)gg.y0; e[8] = (uint32_t)gg.x1; e[9] = (uint32_t)gg.y1;
+                e[10] = gg.exact ? 1u : 0u; e[11] = idx; e[12] = my_cum; e[13] = key0;
+            }
+        }
     }
     s_cum[threadIdx.x] = my_cum;
     s_id[threadIdx.x] = idx;
@@ -877,51 +899,57 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
             flat_ids[p] = s_id[lo];
         }
     }
-    if (TIGHT) {
-        // Splats with more tile rows than the block's row table holds (big splats: few Gaussians at
-        // a high resolution, early training): one WAVE per splat.  Lane = tile row: the spans of 64
-        // rows are computed at once and scanned, then the lanes write the keys of those rows side by
-        // side.  (They used to walk the rows from the top for EVERY key: 1.38 ms of a 3.0 ms step
-        // at 260 k Gaussians and 1080p.)
-        __shared__ uint32_t s_wcum[4][65];
-        __shared__ uint16_t s_wtx0[4][64];
-        const int wv = threadIdx.x >> 6, lane = lane_id();
-        int taken = 0;                                                     // the slow splats go round the 4 waves
-        for (int jm = 0; jm < 4; jm++)
-        for (unsigned long long sm = s_slowmask[jm]; sm; sm &= sm - 1ull) {
-            const int g = 64 * jm + (int)__builtin_ctzll(sm);
-            if ((taken++ & 3) != wv) continue;                             // wave-uniform
-            const SpanGeom geo = s_geo[g];
-            const int rows = geo.y1 - geo.y0;
-            uint32_t outbase = s_cum[g];
-            for (int r0 = 0; r0 < rows; r0 += 64) {
-                int tx0 = 0, len = 0;
-                if (r0 + lane < rows) row_span(geo, geo.y0 + r0 + lane, tile_size, H, tx0, len);
-                uint32_t inc = wave_incl_scan_u32((uint32_t)len);
-                uint32_t total = __shfl(inc, 63, 64);
-                s_wcum[wv][lane] = inc - (uint32_t)len;
-                s_wtx0[wv][lane] = (uint16_t)tx0;
-                if (lane == 63) s_wcum[wv][64] = total;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // same-wave LDS hand-off
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t q = lane; q < total; q += 64) {
-                    int lo = 0, hi = 63;                                    // last row whose first key is <= q
+}
+
+// Emission of the big splats listed by tile_emit_kernel: one wave per splat, waves stride over the list.
+// Lane = tile row: the spans of 64 rows are computed at once and scanned, then the lanes write the keys
+// of those rows side by side.  (Walking the rows from the top for every key, as the first version did
+// inside tile_emit, cost 1.38 ms of a 3.0 ms step at 260 k Gaussians and 1080p.)
+__global__ __launch_bounds__(256) void tile_emit_slow_kernel(const uint32_t* __restrict__ slow_list,
+                                                             const uint32_t* __restrict__ slow_count, int tile_size,
+                                                             int tw, int H, uint32_t cap,
+                                                             uint32_t* __restrict__ tile_keys,
+                                                             uint32_t* __restrict__ flat_ids) {
+    __shared__ uint32_t s_wcum[4][65];
+    __shared__ uint16_t s_wtx0[4][64];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_slow = *slow_count;
+    for (uint32_t ei = blockIdx.x * 4 + wv; ei < n_slow; ei += gridDim.x * 4) {
+        const uint32_t* e = slow_list + (size_t)ei * SLOW_WORDS;
+        SpanGeom geo;
+        geo.mx = __uint_as_float(e[0]); geo.my = __uint_as_float(e[1]); geo.A = __uint_as_float(e[2]);
+        geo.B = __uint_as_float(e[3]); geo.C = __uint_as_float(e[4]); geo.tau2 = __uint_as_float(e[5]);
+        geo.x0 = (int)e[6]; geo.y0 = (int)e[7]; geo.x1 = (int)e[8]; geo.y1 = (int)e[9];
+        geo.exact = e[10] != 0u;
+        const uint32_t id = e[11], key0 = e[13];
+        uint32_t outbase = e[12];
+        const int rows = geo.y1 - geo.y0;
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            int tx0 = 0, len = 0;
+            if (r0 + lane < rows) row_span(geo, geo.y0 + r0 + lane, tile_size, H, tx0, len);
+            uint32_t inc = wave_incl_scan_u32((uint32_t)len);
+            uint32_t total = __shfl(inc, 63, 64);
+            s_wcum[wv][lane] = inc - (uint32_t)len;
+            s_wtx0[wv][lane] = (uint16_t)tx0;
+            if (lane == 63) s_wcum[wv][64] = total;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // same-wave LDS hand-off
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t q = lane; q < total; q += 64) {
+                int lo = 0, hi = 63;                                    // last row whose first key is <= q
 #pragma unroll
-                    for (int it = 0; it < 6; it++) {
-                        int mid = (lo + hi + 1) >> 1;
-                        if (s_wcum[wv][mid] <= q) lo = mid; else hi = mid - 1;
-                    }
-                    uint32_t key = s_key0[g] + (uint32_t)((geo.y0 + r0 + lo) * tw) + (uint32_t)s_wtx0[wv][lo] +
-                                   (q - s_wcum[wv][lo]);
-                    uint32_t p = outbase + q;
-                    if (p < cap) {
-                        tile_keys[p] = key;
-                        flat_ids[p] = s_id[g];
-                    }
+                for (int it = 0; it < 6; it++) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (s_wcum[wv][mid] <= q) lo = mid; else hi = mid - 1;
                 }
-                __builtin_amdgcn_wave_barrier();
-                outbase += total;
+                uint32_t key = key0 + (uint32_t)((geo.y0 + r0 + lo) * tw) + (uint32_t)s_wtx0[wv][lo] + (q - s_wcum[wv][lo]);
+                uint32_t p = outbase + q;
+                if (p < cap) {
+                    tile_keys[p] = key;
+                    flat_ids[p] = id;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            outbase += total;
         }
     }
 }
@@ -974,7 +1002,7 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
 }
 
 struct BinWs {
-    uint32_t *tiles, *dkeys_a, *dkeys_b, *ids_a, *ids_b, *cum, *n_isect, *tmp;
+    uint32_t *tiles, *dkeys_a, *dkeys_b, *ids_a, *ids_b, *cum, *n_isect, *slow, *tmp;
     uint32_t *tk_b, *fi_b;
 };
 
@@ -990,13 +1018,14 @@ size_t bin_ws_layout(uint32_t CN, uint32_t cap, uint32_t* base, BinWs* ws) {
     uint32_t* ib = take(CN);
     uint32_t* cum = take(CN);
     uint32_t* ni = take(16);
+    uint32_t* slow = take((size_t)CN * SLOW_WORDS);
     size_t t1 = rs_tmp_u32(CN), t2 = rs_tmp_u32(cap), t3 = scan_tmp_u32(CN);
     size_t tm = t1 > t2 ? t1 : t2;
     if (t3 > tm) tm = t3;
     uint32_t* tmp = take(tm);
     uint32_t* tkb = take(cap);
     uint32_t* fib = take(cap);
-    if (ws) { *ws = BinWs{tiles, dka, dkb, ia, ib, cum, ni, tmp, tkb, fib}; }
+    if (ws) { *ws = BinWs{tiles, dka, dkb, ia, ib, cum, ni, slow, tmp, tkb, fib}; }
     return o * sizeof(uint32_t);
 }
 
@@ -1086,14 +1115,20 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_emit: workspace too small");
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
-    if (tight)
+    uint32_t* slow_count = ws.n_isect + 4;
+    if (tight) {
+        MI_HIP(hipMemsetAsync(slow_count, 0, 4, st));
         MI_LAUNCH("tile_emit", (tile_emit_kernel<true, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
                   ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
-                  nullptr, nullptr, nullptr);
-    else
+                  nullptr, nullptr, nullptr, ws.slow, slow_count);
+        MI_LAUNCH("tile_emit_slow", tile_emit_slow_kernel, dim3(SLOW_BLOCKS), dim3(256), 0, st, ws.slow, slow_count, tile_size,
+                  tile_width, height, cap, tk, fi);
+    } else {
         MI_LAUNCH("tile_emit", (tile_emit_kernel<false, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
                   ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
-                  nullptr, nullptr, nullptr);
+                  nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
+    MI_LAUNCH_CHECK();
     return bin_sort_and_offsets(ws, tk, fi, n_isect_dev, cap, n_tiles_total, splats, isect_offsets, isect_ids_opt, st);
 }
 
@@ -1139,17 +1174,21 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     unsigned long long* status = reinterpret_cast<unsigned long long*>(ws.cum);
     uint32_t* counter = ws.cum + 2 * (size_t)nblocks;
     uint32_t* err = async_err_ptr();
-    MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 2) * sizeof(uint32_t), st));
+    uint32_t* slow_count = counter + 2;                    // cleared by the same memset as the chain state
+    MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 4) * sizeof(uint32_t), st));
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     if (tight)
         MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
-                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, ws.slow, slow_count);
     else
         MI_LAUNCH("tile_emit", (tile_emit_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
-                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, nullptr, nullptr);
+    if (tight)
+        MI_LAUNCH("tile_emit_slow", tile_emit_slow_kernel, dim3(SLOW_BLOCKS), dim3(256), 0, st, ws.slow, slow_count, tile_size,
+                  tile_width, height, cap, tk, fi);
     MI_LAUNCH_CHECK();
     return bin_sort_and_offsets(ws, tk, fi, n_isect_dev, cap, n_tiles_total, splats, isect_offsets, isect_ids_opt, st);
 }
