@@ -341,6 +341,11 @@ class Trainer:
                 x = graveyard.pop(0)
                 held -= x.numel() * x.element_size()
 
+        # scatter some holes first: on a device whose free memory is one untouched expanse every candidate
+        # lands in much the same relative position (such boxes never got below 600 us)
+        blocks = [torch.empty(48 << 20, dtype=torch.uint8, device=self.device) for _ in range(min(48, hold_budget >> 27))]
+        graveyard.extend(blocks[0::2])
+        del blocks
         shared = [(self.__dict__, k) for k in ("splats", "v_splats", "radii")] + [(self.stats, k) for k in self.stats]
         spare = [bk for i, bk in enumerate(m.banks) if i != m.cur]
         for bk in spare:                          # the spare bank has to hold real parameters while it is timed
@@ -380,7 +385,9 @@ class Trainer:
                         if ob != b:
                             best[ob] = timed(obank)
             # good enough = the kernel s algorithmic bytes at 5.9 TB/s (the best layouts seen reach 5.7)
-            if max(best) <= target_ms or time.time() - t_start > budget_s:
+            # a layout that is still more than 8 % off the target gets a second helping of the budget
+            limit = budget_s * (2.0 if min(best) > 1.08 * target_ms else 1.0)
+            if max(best) <= target_ms or time.time() - t_start > limit:
                 break
         for b in range(len(m.banks)):
             report[f"bank{b}_first_us"], report[f"bank{b}_tuned_us"] = first[b] * 1e3, best[b] * 1e3
