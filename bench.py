@@ -111,9 +111,10 @@ def build_workload(args, rank, dev):
     torch.cuda.empty_cache()
     n = g.params["means"].shape[0]
     cfg = trainer.TrainConfig(
-        max_steps=30_000, capacity=n,
-        # fixed-N workload: statistics are accumulated every step (their cost is in the step),
-        # the every-100-steps refine pass is timed separately below
+        max_steps=30_000, capacity=n + n // 8,
+        # fixed-N workload: the densify statistics are accumulated every step (their cost is inside the
+        # step); the every-100-steps refine pass is NOT inside the timed steps -- main() times one
+        # refine() after them and reports `refine_ms` and the amortised rate next to `value`
         refine_start_iter=10 ** 9,
         max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning)
     tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
@@ -276,6 +277,12 @@ def main():
         dt = float(t.item())
     its = world * args.steps / dt
     log(f"{its:.2f} it/s")
+    # a chained kernel that gave up waiting, or a tile list cut at the capacity, would have made the
+    # timed steps wrong without failing them: the number is only published if the sticky word is clean
+    async_bits = _lib.async_errors()
+    if async_bits:
+        raise SystemExit(f"bench: device error word {async_bits:#x} after the timed region (1/2: a chained kernel "
+                         "gave up waiting, 4: tile intersections exceeded isect_capacity); no result published")
 
     # ---- render-only FPS (same scene, SH degree 3), untimed-region extra
     torch.cuda.synchronize()
@@ -285,6 +292,9 @@ def main():
         tr.render(tr.viewmats[i % V], tr.Ks[i % V])
     torch.cuda.synchronize()
     fps = nr / (time.perf_counter() - t1)
+    async_bits |= _lib.async_errors()
+    if async_bits:
+        raise SystemExit(f"bench: device error word {async_bits:#x} after the render loop; no result published")
 
     result = None
     if rank == 0:
@@ -292,7 +302,7 @@ def main():
         Px = sc.width * sc.height
         n_isect = int(tr.last["binning"]["n_isect"].item())
         n_vis = int((tr.radii[:, :n] > 0).all(-1).sum().item())
-        stages, roof = {}, None
+        stages, roof, render_roof = {}, None, None
         if not args.no_stage_profile:
             # per-kernel launch times: HIP events recorded by the library itself on the launch
             # stream around every kernel (include/mi3dgs.h: mi3dgs_profile_enable)
@@ -343,13 +353,19 @@ def main():
                     stages[k]["alg_flop_per_launch"] = f
                     stages[k]["alg_TFLOPs"] = f / (stages[k]["us_per_launch"] * 1e-6) / 1e12
             dom = max((k for k in stages if k in alg), key=lambda k: stages[k]["ms_per_step"])
-            traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured offline with rocprofv3 --pmc
-            if os.path.isfile(pmc):
-                # measured on the default workload only; tags like "rs_scatter/isect" map to the kernel name
-                if args.scene == "garden" and not args.n:
-                    traffic = json.load(open(pmc)).get(dom.split("/")[0], {}).get("hbm_bytes_per_launch")
-            common = dict(kernel=dom, traffic=traffic, us_per_launch=stages[dom]["us_per_launch"],
+            pmc_tab = json.load(open(pmc)) if os.path.isfile(pmc) and args.scene == "garden" and not args.n else {}
+
+            def offline_traffic(tag):
+                # HBM bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+                # separate runs of this command, gfx950 correction applied; tools/profile_round.sh).  NOT measured
+                # in this run: `traffic_source` says so.  Default workload only.
+                return pmc_tab.get(tag.split("/")[0], {}).get("hbm_bytes_per_launch")
+
+            traffic = offline_traffic(dom)
+            common = dict(kernel=dom, traffic=traffic,
+                          traffic_source="profiles/pmc_traffic.json (offline rocprofv3 --pmc passes of this command)" if traffic else None,
+                          us_per_launch=stages[dom]["us_per_launch"],
                           launches_per_step=stages[dom]["launches_per_step"], alg_bytes_per_launch=alg[dom],
                           alg_GBps=stages[dom]["alg_GBps"], hbm_frac=stages[dom]["alg_GBps"] / HBM_PEAK_GBS)
             if dom in flop:
@@ -361,11 +377,48 @@ def main():
             else:
                 ach = stages[dom]["alg_GBps"]
                 roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, **common)
+            # ---- the render path's dominant kernel, same accounting (its own profiled launches)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            for i in range(iters):
+                tr.render(tr.viewmats[i % V], tr.Ks[i % V])
+            rprof = _lib.profile_read()
+            _lib.profile_enable(False)
+            rdom = max((k for k in rprof if k in alg), key=lambda k: rprof[k][1])
+            rus = 1e3 * rprof[rdom][1] / rprof[rdom][0]
+            lb = tr.last_binning
+            lid = tr.raster_out["last_ids"][0].long()
+            al = tr.raster_out["alphas"][0, ..., 0]
+            offs = lb["isect_offsets"][0].long()
+            tstart = offs.repeat_interleave(16, 0).repeat_interleave(16, 1)[: sc.height, : sc.width]
+            rpairs = int(((lid - tstart + 1) * (al > 0)).sum().item())
+            if rdom == "rasterize_fwd":
+                ach = 20.0 * rpairs / (rus * 1e-6) / 1e12
+                render_roof = dict(kernel=rdom, bound="mfma", achieved=ach, peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                   frac=ach / F32_PEAK_TFLOPS, pairs=rpairs, us_per_launch=rus,
+                                   traffic=offline_traffic(rdom))
+            else:
+                ach = alg[rdom] / (rus * 1e-6) / 1e9
+                render_roof = dict(kernel=rdom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=ach / HBM_PEAK_GBS, us_per_launch=rus, alg_bytes_per_launch=alg[rdom],
+                                   traffic=offline_traffic(rdom))
+            render_roof["ms_per_frame_kernels"] = sum(v[1] for v in rprof.values()) / iters
         cpu = None
         log("stage profile done; cpu baseline")
         if not args.no_cpu_baseline and world == 1:        # the CPU leg runs at N = 1 only
             cpu = cpu_baseline(sc, tr, 0)
             log(f"cpu baseline: {cpu.get('value')}")
+        # ---- one densify / prune pass at this size (every refine_every = 100 steps in training): decide +
+        # scan + scatter of all parameter and moment rows into the spare bank + the host sync on the new count
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rinfo = tr.refine(do_grow=True)
+        torch.cuda.synchronize()
+        refine_ms = 1e3 * (time.perf_counter() - t2)
+        step_ms = 1e3 * dt / args.steps
+        refine = dict(refine_ms=refine_ms, refine_every=100, **{k: rinfo[k] for k in ("n_before", "n_after", "n_dup", "n_split", "n_prune")},
+                      amortised_it_per_s=world * 1e3 / (step_ms + refine_ms / 100.0))
+        log(f"refine: {refine_ms:.2f} ms ({rinfo['n_before']} -> {rinfo['n_after']} Gaussians)")
         result = {
             "metric": "3DGS training iterations/s @1080p (render FPS reported alongside)",
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,7 +428,8 @@ def main():
                                    "one independent scene per GPU", "gaussians": n, "visible": n_vis,
                        "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
                        "parallelism": f"scene-per-gpu x{world}"},
-            "render_fps": fps, "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+            "render_fps": fps, "roofline": roof, "render_roofline": render_roof, "refine": refine,
+            "async_errors": async_bits, "cpu_baseline": cpu, "stages": stages,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

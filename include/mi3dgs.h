@@ -126,14 +126,16 @@ int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float* splats, in
  * isect_ids_opt[max_isect] int64 (nullable): gsplat's (tile << 32 | depth bits) keys. */
 int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int tile_size,
                     int tile_width, int tile_height, int height, int tight,
-                    const int32_t* n_isect_dev, long long max_isect,
+                    int32_t* n_isect_dev /* in/out: clamped to max_isect */, long long max_isect,
                     int32_t* flatten_ids, int32_t* tile_keys, int32_t* isect_offsets,
                     int64_t* isect_ids_opt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Both phases in one call for callers that bring a capacity (no count to read back): depth sort,
  * then counting and emission fused in one chained pass over the depth-sorted splats (no separate
  * tile_count / scan, the row tables are built once).  Outputs as above; n_isect_dev receives the
- * (uncapped) number of intersections, tiles_per_gauss_opt[C*N] is nullable.  depth_keys_opt[C*N]
+ * number of intersections CLAMPED to max_isect (so that no later kernel walks past the buffers);
+ * when the true count was larger, bit 2 of the sticky word of mi3dgs_async_errors() is set and
+ * the lists are truncated.  tiles_per_gauss_opt[C*N] is nullable.  depth_keys_opt[C*N]
  * (nullable): the sort keys mi3dgs_project_fwd wrote (depth bits, 0xFFFFFFFF for culled splats);
  * CONSUMED (the sort ping-pongs through the buffer).  Without it the keys are gathered from the
  * splat records. */
@@ -156,7 +158,9 @@ int mi3dgs_debug_set_sort_mode(int mode);
 /* The chained kernels (onesweep radix pass, device-wide scan, fused tile emit) wait on one another
  * with BOUNDED spins; a wait that runs out sets a bit in one device word instead of hanging the
  * GPU, and the results of that call are then wrong.  This reads (and optionally clears) the word;
- * it synchronises, so call it where the host waits anyway.  0 = every chain resolved. */
+ * it synchronises, so call it where the host waits anyway.  0 = every chain resolved.
+ * Bits: 1 = onesweep radix pass, 2 = chained scan / fused tile emit, 4 = more tile intersections
+ * than `max_isect` (lists truncated; size the capacity up). */
 int mi3dgs_async_errors(uint32_t* out, int reset);
 size_t mi3dgs_scan_workspace_bytes(long long n);
 int mi3dgs_scan_exclusive_u32(const uint32_t* in, uint32_t* out, long long n,

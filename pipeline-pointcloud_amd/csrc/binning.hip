@@ -186,6 +186,7 @@ int scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* 
         return 0;
     }
     uint32_t nb = mi_div_up(n, SCAN_TILE);
+    MI_REQUIRE(async_err_ptr(), "scan: no device error word");
     MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)2 * nb + 2) * sizeof(uint32_t), st));
     MI_LAUNCH(tag, scan_chained_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, out,
               reinterpret_cast<unsigned long long*>(tmp), tmp + 2 * (size_t)nb, async_err_ptr(), total_out);
@@ -534,6 +535,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         uint32_t* ghist = tmp;
         uint32_t* counters = tmp + OS_MAX_PASSES * 256;
         uint32_t* err = async_err_ptr();
+        MI_REQUIRE(err, "sort: no device error word");
         unsigned long long* status = reinterpret_cast<unsigned long long*>(tmp + OS_MAX_PASSES * 256 + 16);
         // one clear per sort call: histograms, counters, and the status table (epochs 1..passes)
         MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B) * sizeof(uint32_t), st));
@@ -830,7 +832,13 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
             uint32_t excl = chain_lookback(status, blk, total, (int)threadIdx.x, chain_err);
             if (threadIdx.x == 0) {
                 s_base = excl;
-                if (blk == gridDim.x - 1) *n_isect_out = excl + total;
+                if (blk == gridDim.x - 1) {
+                    // the count every later kernel (sort, offsets, rasterisers) reads is clamped to the
+                    // capacity of the buffers; an overflow is reported through the sticky error word (bit 2)
+                    uint32_t tot = excl + total;
+                    if (tot > cap) { atomicOr(chain_err, 4u); tot = cap; }
+                    *n_isect_out = tot;
+                }
             }
         }
         __syncthreads();
@@ -1008,6 +1016,11 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
     out[i] = ((int64_t)keys[i] << 32) | (int64_t)d;
 }
 
+// two-phase path: mi3dgs_bin_count left the unclamped total; clamp it to the buffers' capacity
+__global__ void clamp_count_kernel(uint32_t* n_isect, uint32_t cap, uint32_t* err) {
+    if (*n_isect > cap) { *n_isect = cap; atomicOr(err, 4u); }
+}
+
 struct BinWs {
     uint32_t *tiles, *dkeys_a, *dkeys_b, *ids_a, *ids_b, *cum, *n_isect, *slow, *tmp;
     uint32_t *tk_b, *fi_b;
@@ -1105,7 +1118,7 @@ static int bin_sort_and_offsets(const BinWs& ws, uint32_t* tk, uint32_t* fi, con
 }
 
 extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* splats, int tile_size, int tile_width,
-                               int tile_height, int height, int tight, const int32_t* n_isect_dev, long long max_isect,
+                               int tile_height, int height, int tight, int32_t* n_isect_dev, long long max_isect,
                                int32_t* flatten_ids,
                                int32_t* tile_keys, int32_t* isect_offsets, int64_t* isect_ids_opt, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -1120,6 +1133,9 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
     BinWs ws;
     size_t need = bin_ws_layout(CN, cap, (uint32_t*)workspace, &ws);
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_emit: workspace too small");
+    uint32_t* err = async_err_ptr();
+    MI_REQUIRE(err, "bin_emit: no device error word");
+    MI_LAUNCH("clamp_count", clamp_count_kernel, dim3(1), dim3(1), 0, st, (uint32_t*)n_isect_dev, cap, err);
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     uint32_t* slow_count = ws.n_isect + 4;
@@ -1181,6 +1197,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     unsigned long long* status = reinterpret_cast<unsigned long long*>(ws.cum);
     uint32_t* counter = ws.cum + 2 * (size_t)nblocks;
     uint32_t* err = async_err_ptr();
+    MI_REQUIRE(err, "bin_tiles: no device error word");
     uint32_t* slow_count = counter + 2;                    // cleared by the same memset as the chain state
     MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 4) * sizeof(uint32_t), st));
     uint32_t* tk = (uint32_t*)tile_keys;

@@ -140,6 +140,22 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     return 99.0 if mse <= 1e-12 else -10.0 * math.log10(mse)
 
 
+class ViewOrder:
+    """Training view of global slot `s` (= step * world + rank): epoch e = s // V walks a permutation of
+    the V views drawn from (seed, e) alone, so every rank derives the same order without talking, the
+    ranks of one step get `world` different views, and a full epoch touches each view exactly once."""
+
+    def __init__(self, n_views: int, seed: int):
+        self.V, self.seed, self._epoch, self._perm = int(n_views), int(seed), -1, None
+
+    def __call__(self, slot: int) -> int:
+        e = slot // self.V
+        if e != self._epoch:
+            g = torch.Generator().manual_seed((self.seed * 1000003 + e * 7919 + 1) & 0x7FFFFFFF)
+            self._perm, self._epoch = torch.randperm(self.V, generator=g).tolist(), e
+        return self._perm[slot % self.V]
+
+
 def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int = 100, save_steps=(),
                  on_save=None, strategy: str = "default", cap_max: int = 1_000_000, init_opacity: float = 0.1,
                  init_scale: float = 1.0) -> Tuple[object, object, Dict]:
@@ -175,10 +191,9 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     say(f"loaded in {time.time() - t0:.1f}s; training {cfg.max_steps} steps from {tr.model.n} Gaussians "
         f"(capacity {tr.model.capacity})")
     V = len(ds.train_idx)
-    g = torch.Generator().manual_seed(cfg.seed)
-    order = torch.randperm(V, generator=g).tolist()
     world = ctx.world if ctx is not None and ctx.active else 1
     rank = ctx.rank if ctx is not None else 0
+    view_of = ViewOrder(V, cfg.seed)
     t_train = time.time()
     t_last, s_last = t_train, 0
     from . import _lib
@@ -195,11 +210,8 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
             say(f"profile of steps {prof_a}..{prof_b}: {tot / (prof_b - prof_a):.3f} ms of kernels per step")
             for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[:14]:
                 say(f"  {k:24s} {v[1] / (prof_b - prof_a):7.3f} ms/step  {v[0] / (prof_b - prof_a):5.1f} launches  {1e3 * v[1] / max(v[0], 1):8.1f} us each")
-        slot = step * world + rank
-        if slot % V == 0 and slot > 0:
-            order = torch.randperm(V, generator=g).tolist()
         want = (step % log_every == 0) or step == cfg.max_steps - 1
-        loss = tr.step(order[slot % V], want_loss=want)
+        loss = tr.step(view_of(step * world + rank), want_loss=want)
         if want and rank == 0:
             now = time.time()
             rate = (step - s_last + 1) / max(now - t_last, 1e-9)
@@ -210,6 +222,7 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
         if (step + 1) in save_steps and on_save is not None:
             on_save(tr, ds, step)
     torch.cuda.synchronize()
+    tr.check_async_errors()                # chained kernels that gave up / truncated tile lists since the last refine
     train_s = time.time() - t_train
     stats = dict(train_seconds=train_s, iters_per_sec=cfg.max_steps / max(train_s, 1e-9), gaussians=tr.model.n)
     if ds.eval_idx and rank == 0:
@@ -314,6 +327,14 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
                                  init_opacity=0.5 if a["strategy"] == "mcmc" else 0.1,
                                  init_scale=0.1 if a["strategy"] == "mcmc" else 1.0)
     save(tr, ds, cfg.max_steps - 1)            # every rank holds the full (replicated) model
+    # The reference's exporter converts sorted(os.listdir(ckpts))[-1] (gsplat_pt_to_ply.py:36-40), a
+    # LEXICOGRAPHIC sort: with scaled step counts an intermediate "ckpt_874_rank0.pt" sorts after the
+    # final "ckpt_3749_rank0.pt".  Drop this rank's intermediates that would shadow the final one.
+    final_name = f"ckpt_{cfg.max_steps - 1}_rank{rank}.pt"
+    for s_ in save_steps:
+        name = f"ckpt_{s_ - 1}_rank{rank}.pt"
+        if name != final_name and name > f"ckpt_{cfg.max_steps - 1}_rank" and os.path.isfile(os.path.join(ck_dir, name)):
+            os.remove(os.path.join(ck_dir, name))
     if rank == 0:
         os.makedirs(os.path.join(a["result_dir"], "stats"), exist_ok=True)
         with open(os.path.join(a["result_dir"], "stats", f"val_step{cfg.max_steps - 1:04d}.json"), "w") as f:
@@ -325,12 +346,24 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
         dist.destroy_process_group()
 
 
+def _visible_gpus() -> int:
+    """GPUs this launcher spreads over (MI3DGS_FAKE_DEVICE_COUNT: launcher tests on a host without GPUs)."""
+    fake = os.environ.get("MI3DGS_FAKE_DEVICE_COUNT")
+    return int(fake) if fake else torch.cuda.device_count()
+
+
 def main_simple_trainer(argv: Optional[List[str]] = None) -> int:
     """Like gsplat's own launcher: one process per visible GPU (it ignores torchrun's env)."""
     a = parse_simple_trainer(sys.argv[1:] if argv is None else argv)
-    world = torch.cuda.device_count()
-    if a["strategy"] == "mcmc":
-        world = 1                      # the mcmc strategy is single-GPU for now
+    world = _visible_gpus()
+    if a["strategy"] == "mcmc" and world > 1:
+        # The mcmc strategy runs on one GPU for now.  The reference still passes --steps_scaler 1/G
+        # (main.py:1322-1327: G images per step upstream, so 1/G of the steps); with one image per step
+        # that would train 1/G of the job, so the division is undone here.
+        a["steps_scaler"] = min(1.0, a["steps_scaler"] * world)
+        say(f"mcmc: training on one of the {world} visible GPUs; --steps_scaler reset to {a['steps_scaler']:g} "
+            "(one image per step)")
+        world = 1
     if world <= 1:
         _simple_trainer_rank(0, 1, 0, a)
         return 0

@@ -128,6 +128,16 @@ class DataParallelTrainer(Trainer):
     def _all_reduce_grads(self):
         allreduce_mean_(self._live_grads(), self.ctx)
 
+    def _async_error_bits(self) -> int:
+        # every rank must take the same decision, or the ones that do not raise hang in the next collective
+        bad = super()._async_error_bits()
+        if self.ctx.active:
+            dev = self.device if dist.get_backend(self.ctx.group) == "nccl" else "cpu"
+            t = torch.tensor([(bad >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)   # RCCL has no bitwise OR
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.ctx.group)
+            bad = sum(int(v) << b for b, v in enumerate(t.tolist()))
+        return bad
+
     def refine(self, do_grow: bool = True):
         n = self.model.n
         allreduce_stats_({k: v[:n] for k, v in self.stats.items()}, self.ctx)

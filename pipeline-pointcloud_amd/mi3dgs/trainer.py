@@ -425,12 +425,25 @@ class Trainer:
         if step % c.reset_every == 0 and step > 0:
             self.reset_opacity()
 
+    def _async_error_bits(self) -> int:
+        """The device's sticky error word (synchronises).  The data-parallel trainer ORs it over the ranks."""
+        return ops._lib.async_errors()
+
+    def check_async_errors(self) -> None:
+        """Raises if, since the last check, a chained kernel's bounded wait ran out (bits 1, 2: wrong
+        offsets downstream) or a view produced more tile intersections than `max_isect` (bit 4: lists
+        truncated).  Call it where the host waits anyway: refine, end of training, end of a benchmark."""
+        bad = self._async_error_bits()
+        if bad & 3:
+            raise ops._lib.Mi3dgsError(f"a chained kernel gave up waiting (bits {bad:#x}); results since the last check are invalid")
+        if bad & 4:
+            raise ops._lib.Mi3dgsError(f"tile intersections exceeded the capacity max_isect={self.cfg.max_isect}: "
+                                       f"lists were truncated since the last check (bits {bad:#x})")
+
     def refine(self, do_grow: bool = True) -> Dict[str, int]:
         """One densify+prune pass; returns counts.  One host sync (the new Gaussian count)."""
         c, m = self.cfg, self.model
-        bad = ops._lib.async_errors()                # the host waits here anyway: did every chained kernel resolve?
-        if bad:
-            raise ops._lib.Mi3dgsError(f"a chained kernel gave up waiting (bits {bad:#x}); results since the last check are invalid")
+        self.check_async_errors()                    # the host waits here anyway: did every chained kernel resolve?
         n = m.n
         st = ops._stream(self.device)
         flags, counts, offs = self.flags_buf[:n], self.count_buf[:n], self.offs_buf[:n]
