@@ -183,6 +183,11 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
                          const float* v_render, const float* v_alphas, int absgrad, float* v_splats,
                          void* stream);
 
+/* A/B switch: 1 (default) = the rasterisers whose pixel x splat quadratic forms run on the matrix pipe
+ * (v_mfma_f32_32x32x2_f32, csrc/rasterize_mfma.hip), 0 = the round-1 all-VALU kernels.  Forward and
+ * backward must run in the same mode. */
+int mi3dgs_debug_set_raster_mode(int mode);
+
 /* ---- loss ----------------------------------------------------------------------------
  * Replaces the L1 + SSIM(11x11, sigma 1.5) loss of splatfacto / simple_trainer.
  * sums[2] (zeroed by the caller) receives {sum |r-t|, sum SSIM map}; the three dm_* maps

@@ -276,10 +276,13 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width: int, height: 
                 if backgrounds is not None:
                     rgb = rgb + T_fin[:, None] * backgrounds[c][None, :]
                 rows.append((c, py.flatten(), px.flatten(), rgb, 1.0 - T_fin, last))
-    for c, py, px, rgb, a, last in rows:
-        render[c, py, px] = rgb
-        alphas[c, py, px, 0] = a
-        last_ids[c, py, px] = last.to(torch.int32)
+    if rows:
+        # one scatter for all tiles (a per-tile in-place write makes autograd carry a full-size image per tile)
+        pix = torch.cat([(c * height + py) * width + px for c, py, px, _, _, _ in rows])
+        render = render.reshape(-1, D).index_put((pix,), torch.cat([r[3] for r in rows])).reshape(C, height, width, D)
+        alphas = alphas.reshape(-1).index_put((pix,), torch.cat([r[4] for r in rows])).reshape(C, height, width, 1)
+        last_ids = last_ids.reshape(-1).index_put((pix,), torch.cat([r[5] for r in rows]).to(torch.int32)).reshape(
+            C, height, width)
     return render, alphas, last_ids
 
 

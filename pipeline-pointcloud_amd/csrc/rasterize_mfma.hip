@@ -1,0 +1,424 @@
+// Tile rasteriser, forward and backward, with the pixel x splat quadratic forms on the MATRIX pipe.
+// gfx950 only.  Replaces gsplat rasterize_to_pixels_{fwd,bwd}, reached by the
+// reference only through main.py:1312 / main.py:1343.
+//
+// What is a matrix product here.  For a pixel p of a tile and a splat s of its list
+//     log2 alpha(s, p) = log2 o_s - log2e * sigma(s, p)
+//                      = c0 u^2 + c1 uv + c2 v^2 + c3 u + c4 v + c5,     (u, v) = p - tile centre,
+// a [32 splats x 6] . [6 x 64 pixels] product with NO padding in K on v_mfma_f32_32x32x2_f32 (K = 2 per
+// instruction, three accumulating instructions per 32 pixels): 12 matrix-pipe cycles per (wave, splat)
+// visit beside the vector pipe, instead of the 5 (backward: 7) VALU instructions per visit that evaluated
+// dx, dy and the conic.  Both rasterisers were 100 % VALU-issue bound (round 1, DESIGN.md finding 16).
+// The six coefficients are computed once per (tile, splat) when the record is staged into LDS
+// (quad_coefs, tile-centre coordinates keep |u|, |v| <= 7.5 so the f32 chain cancels to ~2e-4 in log2
+// units at worst); the per-pixel basis is six registers per lane for the whole kernel.
+//
+// Layout.  A = coefficients (row = splat), B = basis (column = pixel).  The C/D map of 32x32 puts one pixel
+// COLUMN on a lane and 16 of the 32 splat ROWS in its registers, the other 16 rows of the same pixel on
+// lane + 32.  A wave owns an 8x8 quadrant = two 32-pixel column blocks X and Y; 16 v_permlane32_swap
+// (half a VALU per visit) exchange X's upper-half rows against Y's lower-half rows, after which EVERY lane
+// owns one pixel and holds all 32 splats of the sub-batch in 32 registers, statically indexed.  The
+// front-to-back chain then runs out of registers.
+//
+// Forward and backward evaluate log2 alpha through the SAME instruction sequence (quad_coefs -> the
+// same three MFMAs -> v_min3 -> v_exp), so the backward's membership test alpha >= 1/255 is the forward's
+// bit for bit (round 1 used exp2 of a pre-scaled conic forward and __expf backward).
+//
+// Backward: what is reduced over the pixels of a quadrant per splat is q = -dL/dsigma and its five
+// moments q u, q v, q u^2, q uv, q v^2 plus the three colour sums (9 values, one reduce-scatter as before);
+// the conic / mean / opacity gradients follow per (tile, splat) from the moments at flush time, so the per-pair
+// products dx^2, dx dy, A dx + B dy ... are gone from the inner loop.
+#include "common.h"
+
+namespace mfma_raster {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;
+constexpr int SUB = 32;                       // splats per MFMA sub-batch
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LOG2_MAX_ALPHA = -0.0014434169f;   // log2(0.999)
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---- the six coefficients of log2 alpha over a tile, shared by both kernels.  contract(off) + explicit
+// fma: the two kernels must round identically whatever their surrounding code looks like.
+__device__ __forceinline__ void quad_coefs(float x, float y, float A, float B, float C, float opac, float xc, float yc,
+                                           float c[6]) {
+#pragma clang fp contract(off)
+    const float a = (-0.5f * LOG2E) * A, b = (-LOG2E) * B, cc = (-0.5f * LOG2E) * C;
+    const float mx = x - xc, my = y - yc;          // splat centre relative to the tile centre; d = (mx - u, my - v)
+    c[0] = a;
+    c[1] = b;
+    c[2] = cc;
+    c[3] = -__builtin_fmaf(2.f * a, mx, b * my);
+    c[4] = -__builtin_fmaf(2.f * cc, my, b * mx);
+    const float tq = __builtin_fmaf(b, my, a * mx);
+    c[5] = __builtin_fmaf(mx, tq, (cc * my) * my) + __builtin_amdgcn_logf(opac);     // v_log_f32 = log2
+}
+
+// LDS image of one staged batch of 256 splats
+struct Staged {
+    float coef[BLOCK / SUB][6][SUB];     // A operands: [sub-batch][k][row]
+    float4 uni[BLOCK];                   // per splat, wave-uniform in the chain: log2 o, r, g, b
+};
+
+__device__ __forceinline__ void stage_splat(Staged& L, int slot, bool live, const float* __restrict__ rec_f, float xc,
+                                            float yc) {
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
+    float4 u = make_float4(-INFINITY, 0.f, 0.f, 0.f);
+    if (live) {
+        const float4* rec = reinterpret_cast<const float4*>(rec_f);
+        const float4 a = rec[0], bb = rec[1];                 // x y A B | C o r g
+        const float cb = rec_f[SP_B];
+        if (bb.y > 0.f) {
+            quad_coefs(a.x, a.y, a.z, a.w, bb.x, bb.y, xc, yc, c);
+            u = make_float4(__builtin_amdgcn_logf(bb.y), bb.z, bb.w, cb);
+        }
+    }
+    const int sb = slot >> 5, row = slot & 31;
+#pragma unroll
+    for (int k = 0; k < 6; k++) L.coef[sb][k][row] = c[k];
+    L.uni[slot] = u;
+}
+
+// per-lane basis operands: for the X block lane l supplies basis_{2q + (l >> 5)} of the pixel that lane (l & 31)
+// owns after the swap, for the Y block of the pixel lane 32 + (l & 31) owns.  Basis k: u^2, uv, v^2, u, v, 1.
+__device__ __forceinline__ float basis_of(int k, float u, float v) {
+    switch (k) {
+        case 0: return u * u;
+        case 1: return u * v;
+        case 2: return v * v;
+        case 3: return u;
+        case 4: return v;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ void pixel_of_lane(int wave, int lane, int& lx, int& ly) {
+    lx = ((wave & 1) << 3) + (lane & 7);
+    ly = ((wave >> 1) << 3) + (lane >> 3);
+}
+
+struct Basis { float bx[3], by[3]; };
+
+__device__ __forceinline__ Basis make_basis(int wave, int lane) {
+    Basis b;
+    const int h = lane >> 5;
+    int lx, ly;
+    pixel_of_lane(wave, lane & 31, lx, ly);
+    float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) b.bx[q] = basis_of(2 * q + h, u, v);
+    pixel_of_lane(wave, 32 + (lane & 31), lx, ly);
+    u = (float)lx - 7.5f; v = (float)ly - 7.5f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) b.by[q] = basis_of(2 * q + h, u, v);
+    return b;
+}
+
+// log2 alpha (opacity folded in, NOT yet clamped) of this lane's pixel against the 32 splats of sub-batch
+// `sb`: s[i] for row i in depth order.
+__device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane, const Basis& b, float s[SUB]) {
+    const int h = lane >> 5, row = lane & 31;
+    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
+    f16v X = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v Y = X;
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], Y, 0, 0, 0);
+    // register r of a 32x32 accumulator = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  swap(X[r], Y[r]) hands X's
+    // upper-half rows to the lower lanes and Y's lower-half rows to the upper lanes: afterwards, on every lane,
+    // X[r] = row (r & 3) + 8 (r >> 2) and Y[r] = that + 4 of the lane's OWN pixel.
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        // (copy the elements out first: __builtin_bit_cast applied directly to `X[r]` reads element 0 for every r
+        // with this clang)
+        const float xv = X[r], yv = Y[r];
+        auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xv), __builtin_bit_cast(unsigned, yv),
+                                                   false, false);
+        const unsigned x_new = sw[0], y_new = sw[1];
+        const float xr = __builtin_bit_cast(float, x_new), yr = __builtin_bit_cast(float, y_new);
+        const int row0 = (r & 3) + 8 * (r >> 2);
+        s[row0] = xr;
+        s[row0 + 4] = yr;
+    }
+}
+
+// alpha of a pair from its log2: min(0.999, o * vis) with sigma clamped at 0 (a PSD form evaluated through
+// the six-term chain can come out a few 1e-5 positive near the splat centre)
+__device__ __forceinline__ float alpha_of(float s, float log2_o) {
+    return __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fminf(s, log2_o), LOG2_MAX_ALPHA));
+}
+
+template <bool HAS_BG>
+__global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
+    int32_t* __restrict__ last_ids) {
+    __shared__ Staged L;
+    const int t = blockIdx.x;
+    const int cam = t / (tw * th);
+    const int tile_in = t - cam * (tw * th);
+    const int ty = tile_in / tw, tx = tile_in - ty * tw;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int lx, ly;
+    pixel_of_lane(wv, lane, lx, ly);
+    const int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
+    const bool inside = px_i < W && py_i < H;
+    const float xc = (float)(tx * TILE) + 8.f, yc = (float)(ty * TILE) + 8.f;     // pixel centre p + 0.5 = centre + (u, v)
+    const Basis basis = make_basis(wv, lane);
+    const int start = tile_offsets[t];
+    const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    int cur = 0;
+    bool done = !inside;
+    for (int bs = start; bs < end; bs += BLOCK) {
+        if (__syncthreads_count(done) == BLOCK) break;
+        const int idx = bs + (int)threadIdx.x;
+        const bool live = idx < end;
+        stage_splat(L, (int)threadIdx.x, live, splats + (size_t)(live ? flatten_ids[idx] : 0) * SPLAT_STRIDE, xc, yc);
+        __syncthreads();
+        const int bsz = min(BLOCK, end - bs);
+        for (int sb = 0; sb * SUB < bsz; sb++) {
+            if (wave_ballot(!done) == 0ull) break;
+            float s[SUB];
+            eval_sub_batch(L, sb, lane, basis, s);
+#pragma unroll
+            for (int i = 0; i < SUB; i++) {
+                if ((i & 7) == 0 && i > 0 && wave_ballot(!done) == 0ull) break;
+                const float4 u = L.uni[sb * SUB + i];
+                const float alpha = alpha_of(s[i], u.x);
+                bool ok = !done && alpha >= ALPHA_THRESHOLD;
+                if (wave_ballot(ok) == 0ull) continue;
+                const float wgt0 = ok ? alpha * T : 0.f;
+                const float nT = T - wgt0;                      // T (1 - alpha)
+                const bool stop = ok && nT <= T_STOP;
+                done = done || stop;
+                ok = ok && !stop;
+                const float wgt = ok ? wgt0 : 0.f;
+                cr = __builtin_fmaf(u.y, wgt, cr);
+                cg = __builtin_fmaf(u.z, wgt, cg);
+                cb = __builtin_fmaf(u.w, wgt, cb);
+                cur = ok ? bs + sb * SUB + i : cur;
+                T = ok ? nT : T;
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        if (HAS_BG) {
+            const float* bg = backgrounds + 3 * cam;
+            cr += T * bg[0]; cg += T * bg[1]; cb += T * bg[2];
+        }
+        render[3 * pix] = cr; render[3 * pix + 1] = cg; render[3 * pix + 2] = cb;
+        alphas[pix] = 1.f - T;
+        last_ids[pix] = cur;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward
+// acc row of a staged slot: moments of q = -dL/dsigma about the tile centre, then the colour sums
+constexpr int AC_QU = 0, AC_QV = 1, AC_QUU = 2, AC_QUV = 3, AC_QVV = 4, AC_Q = 5, AC_R = 6, AC_G = 7, AC_B = 8,
+              AC_ABSX = 9, AC_ABSY = 10, AC_STRIDE = 12;
+
+struct StagedBwd {
+    Staged f;
+    float4 geo[BLOCK];        // mx, my (relative to the tile centre), A, B
+    float2 geo2[BLOCK];       // C, 1 / o
+    int id[BLOCK];
+    float acc[BLOCK][AC_STRIDE];
+    int touched[BLOCK];
+    int wave_max[4];
+};
+
+template <bool HAS_BG, bool ABSGRAD>
+__global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
+    __shared__ StagedBwd L;
+    const int t = blockIdx.x;
+    const int cam = t / (tw * th);
+    const int tile_in = t - cam * (tw * th);
+    const int ty = tile_in / tw, tx = tile_in - ty * tw;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int lx, ly;
+    pixel_of_lane(wv, lane, lx, ly);
+    const int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
+    const bool inside = px_i < W && py_i < H;
+    const float xc = (float)(tx * TILE) + 8.f, yc = (float)(ty * TILE) + 8.f;
+    const float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
+    const float uu = u * u, uv = u * v, vv = v * v;
+    const int start = tile_offsets[t];
+    const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+    if (end <= start) return;
+
+    float T_final = 1.f, vr0 = 0.f, vr1 = 0.f, vr2 = 0.f, va = 0.f;
+    int bin_final = -1;
+    if (inside) {
+        const size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        const float al = alphas[pix];
+        T_final = 1.f - al;
+        bin_final = last_ids[pix];
+        vr0 = v_render[3 * pix]; vr1 = v_render[3 * pix + 1]; vr2 = v_render[3 * pix + 2];
+        va = v_alphas[pix];
+        // a pixel that composited nothing has last_id 0 and alpha 0: mark it so that slot `start` is skipped
+        if (al == 0.f) bin_final = -1;
+    }
+    float tail = T_final * va;                      // T_final (v_alpha - bg . v_rgb)
+    if (HAS_BG) {
+        const float* bg = backgrounds + 3 * cam;
+        tail -= T_final * (bg[0] * vr0 + bg[1] * vr1 + bg[2] * vr2);
+    }
+    int wmax = bin_final;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    if (lane == 0) L.wave_max[wv] = wmax;
+    __syncthreads();
+    const int bmax = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
+    if (bmax < start) return;
+    const Basis basis = make_basis(wv, lane);
+
+    float T = T_final;
+    float buf0 = 0.f, buf1 = 0.f, buf2 = 0.f;
+    for (int be = bmax; be >= start; be -= BLOCK) {
+        // slot k <-> sorted index be - k: rows of a sub-batch run back to front
+        const int idx = be - (int)threadIdx.x;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < AC_STRIDE; k++) L.acc[threadIdx.x][k] = 0.f;
+        L.touched[threadIdx.x] = 0;
+        {
+            const bool live = idx >= start;
+            const int id = live ? flatten_ids[idx] : 0;
+            const float* rec_f = splats + (size_t)id * SPLAT_STRIDE;
+            stage_splat(L.f, (int)threadIdx.x, live, rec_f, xc, yc);
+            if (live) {
+                const float4* rec = reinterpret_cast<const float4*>(rec_f);
+                const float4 a = rec[0], bb = rec[1];
+                L.geo[threadIdx.x] = make_float4(a.x - xc, a.y - yc, a.z, a.w);
+                L.geo2[threadIdx.x] = make_float2(bb.x, bb.y > 0.f ? 1.f / bb.y : 0.f);
+                L.id[threadIdx.x] = id;
+            }
+        }
+        __syncthreads();
+        const int bsz = min(BLOCK, be - start + 1);
+        const int k0 = max(0, be - wmax);            // wave-uniform: nothing in this wave is live before slot k0
+        for (int sb = k0 / SUB; sb * SUB < bsz; sb++) {
+            float s[SUB];
+            eval_sub_batch(L.f, sb, lane, basis, s);
+#pragma unroll
+            for (int i = 0; i < SUB; i++) {
+                const int k = sb * SUB + i;
+                const int sidx = be - k;
+                const float4 un = L.f.uni[k];
+                const float m2 = __builtin_fminf(s[i], un.x);                      // log2 (o vis), sigma clamped at 0
+                const float alpha = __builtin_amdgcn_exp2f(__builtin_fminf(m2, LOG2_MAX_ALPHA));
+                const bool valid = (sidx <= bin_final) && alpha >= ALPHA_THRESHOLD;
+                if (wave_ballot(valid) == 0ull) continue;
+                // branch-free live part: a dead lane runs it with alpha = 0 (ra = 1, T and buf unchanged bit for
+                // bit, every partial 0)
+                const float a_eff = valid ? alpha : 0.f;
+                const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+                T *= ra;
+                const float fac = a_eff * T;
+                float g_r = fac * vr0, g_g = fac * vr1, g_b = fac * vr2;
+                float v_alpha = (un.y * T - buf0 * ra) * vr0 + (un.z * T - buf1 * ra) * vr1 + (un.w * T - buf2 * ra) * vr2;
+                v_alpha += tail * ra;
+                buf0 += un.y * fac; buf1 += un.z * fac; buf2 += un.w * fac;
+                // q = o vis dL/dalpha = -dL/dsigma; zero where the 0.999 clamp is active (alpha == o vis otherwise)
+                const bool grad_on = valid && m2 <= LOG2_MAX_ALPHA;
+                float q = grad_on ? alpha * v_alpha : 0.f;
+                float qu = q * u, qv = q * v, quu = q * uu, quv = q * uv, qvv = q * vv;
+                float g_ax = 0.f, g_ay = 0.f;
+                if (ABSGRAD) {
+                    const float4 ge = L.geo[k];
+                    const float cC = L.geo2[k].x;
+                    const float dx = ge.x - u, dy = ge.y - v;
+                    g_ax = fabsf(q * (ge.z * dx + ge.w * dy));
+                    g_ay = fabsf(q * (ge.w * dx + cC * dy));
+                }
+                // reduce-scatter: lane l ends with the total of value number (l >> 3) in qu, lane 63 with g_b's
+                wave_reduce_scatter8_plus1(qu, qv, quu, quv, qvv, q, g_r, g_g, g_b);
+                if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
+                {
+                    const bool last = lane == 63;
+                    if ((lane & 7) == 0 || last) atomicAdd(&L.acc[k][last ? AC_B : (lane >> 3)], last ? g_b : qu);
+                    if (last) {
+                        if (ABSGRAD) { atomicAdd(&L.acc[k][AC_ABSX], g_ax); atomicAdd(&L.acc[k][AC_ABSY], g_ay); }
+                        L.touched[k] = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush: lane -> (record = lane >> 4, dword = lane & 15): 4 records = 4 x 64-B requests per instruction.
+        // The gradients of (x, y, conic A, B, C, opacity) follow from the moments about the tile centre:
+        //   sum q dx = mx M - Mu, sum q dx^2 = mx^2 M - 2 mx Mu + Muu, ...   (dx = mx - u, dy = my - v)
+        for (int sl = wv * 64; sl < wv * 64 + 64; sl += 4) {
+            const int slot = sl + (lane >> 4);
+            const int comp = lane & 15;
+            if (slot < bsz && L.touched[slot] && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
+                const float* ac = L.acc[slot];
+                const float M = ac[AC_Q], Mu = ac[AC_QU], Mv = ac[AC_QV];
+                const float4 ge = L.geo[slot];
+                const float2 g2 = L.geo2[slot];
+                const float mx = ge.x, my = ge.y;
+                const float sdx = mx * M - Mu, sdy = my * M - Mv;                 // sum q dx, sum q dy
+                float val;
+                switch (comp) {
+                    case GR_X: val = -(ge.z * sdx + ge.w * sdy); break;
+                    case GR_Y: val = -(ge.w * sdx + g2.x * sdy); break;
+                    case GR_CA: val = -0.5f * (mx * (mx * M - 2.f * Mu) + ac[AC_QUU]); break;
+                    case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + ac[AC_QUV]); break;
+                    case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + ac[AC_QVV]); break;
+                    case GR_OPA: val = M * g2.y; break;
+                    case GR_R: val = ac[AC_R]; break;
+                    case GR_G: val = ac[AC_G]; break;
+                    case GR_B: val = ac[AC_B]; break;
+                    case GR_ABSX: val = ac[AC_ABSX]; break;
+                    default: val = ac[AC_ABSY]; break;
+                }
+                atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
+            }
+        }
+    }
+}
+
+}  // namespace mfma_raster
+
+int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
+                          const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st) {
+    using namespace mfma_raster;
+    if (backgrounds)
+        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                  tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids);
+    else
+        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                  tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
+                          const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
+                          const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
+                          const float* v_alphas, int absgrad, float* v_splats, hipStream_t st) {
+    using namespace mfma_raster;
+#define LAUNCH_BWD(BG, AG)                                                                                             \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,    \
+              v_render, v_alphas, v_splats)
+    if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
+    else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+#undef LAUNCH_BWD
+    MI_LAUNCH_CHECK();
+    return 0;
+}

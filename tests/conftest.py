@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "pipeline-pointcloud_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is plain torch on the CPU: a one-GPU box grants 16 cores of a 256-thread host, and torch's
+    # default (one thread per host core) oversubscribes them by an order of magnitude
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, 16)))
 
 
 @pytest.fixture(scope="session")

@@ -27,3 +27,86 @@ def activated(P, dtype=torch.float64):
 def rel_err(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+# ---------------------------------------------------------------- reference-held real splat
+def load_wolf():
+    """The reference's own trained sample `source/Gradio/favorites/wolf.spz` (committed as the data
+    fixture tests/golden/wolf.spz), decoded by the reference's own codec compiled from its sources
+    (oracle/_ref/splat_converter, built by oracle/Makefile; the binary travels to the GPU box).
+    Returns the 90 586 Gaussians in parameter space (checkpoint schema).  Opacity logits the SPZ
+    decoder emits as +-inf (alpha 0 / 255) are clamped to +-12."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from mi3dgs import io_ply
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conv = os.path.join(root, "oracle", "_ref", "splat_converter")
+    if not os.path.isfile(conv):
+        import pytest
+        pytest.skip("oracle/_ref/splat_converter not built (make -C oracle, needs /root/reference)")
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(os.path.join(root, "tests", "golden", "wolf.spz"), os.path.join(td, "wolf.spz"))
+        subprocess.run([conv, os.path.join(td, "wolf.spz")], check=True, stdout=subprocess.DEVNULL)
+        P = io_ply.read_ply(os.path.join(td, "wolf.ply"))
+    P["opacities"] = torch.nan_to_num(P["opacities"], posinf=12.0, neginf=-12.0).clamp(-12.0, 12.0)
+    return {k: v.float().contiguous() for k, v in P.items()}
+
+
+def wolf_scene(n_views=3, width=96, height=64, fx=None, subsample=1):
+    """The wolf seen by a small ring of cameras (it stands around (0.02, -0.53, 0), about 0.7 tall)."""
+    P = load_wolf()
+    if subsample > 1:
+        P = {k: v[::subsample].contiguous() for k, v in P.items()}
+    centre = torch.tensor([0.02, -0.53, 0.0])
+    fx = fx if fx is not None else 1.1 * width
+    vms, ks = [], []
+    for i in range(n_views):
+        a = 2.0 * math.pi * (i + 0.25) / n_views
+        eye = centre + torch.tensor([1.0 * math.cos(a), 0.35, 1.0 * math.sin(a)])
+        vms.append(scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0)))
+        ks.append(scenes._intrinsics(fx, width, height))
+    return scenes.Scene("wolf", P, torch.stack(vms), torch.stack(ks), width, height)
+
+
+def crop_camera(K, x0, y0):
+    """Intrinsics of the window whose top-left pixel is (x0, y0) of the full frame."""
+    Kc = K.clone()
+    Kc[..., 0, 2] -= x0
+    Kc[..., 1, 2] -= y0
+    return Kc
+
+
+# ------------------------------------------------- integer reference of the binning, any device
+def isect_reference(radii, splats, tile_size, tw, th):
+    """gsplat's isect_tiles + 64-bit stable sort + offsets restated with torch ops on the tensors'
+    own device (the GPU at full BASELINE sizes): bounding-box tile lists, key = (camera*tiles+tile)
+    << 32 | depth bits, ties in Gaussian-index order.  Returns tiles_per_gauss, isect_ids,
+    flatten_ids, offsets."""
+    C, N = radii.shape[:2]
+    dev = radii.device
+    ts = float(tile_size)
+    m, r = splats[..., 0:2].float(), radii.float()
+    x0 = torch.clamp(torch.floor((m[..., 0] - r[..., 0]) / ts), 0, tw).long()
+    y0 = torch.clamp(torch.floor((m[..., 1] - r[..., 1]) / ts), 0, th).long()
+    x1 = torch.clamp(torch.ceil((m[..., 0] + r[..., 0]) / ts), 0, tw).long()
+    y1 = torch.clamp(torch.ceil((m[..., 1] + r[..., 1]) / ts), 0, th).long()
+    vis = (radii > 0).all(-1)
+    tiles = torch.where(vis, (x1 - x0) * (y1 - y0), torch.zeros_like(x0))
+    cnt = tiles.flatten()
+    sel = torch.nonzero(cnt > 0).flatten()
+    c = cnt[sel]
+    w = (x1 - x0).flatten()[sel]
+    rep = torch.repeat_interleave(torch.arange(sel.numel(), device=dev), c)
+    start = torch.cumsum(c, 0) - c
+    local = torch.arange(int(c.sum()), device=dev) - start[rep]
+    ty = y0.flatten()[sel][rep] + local // w[rep]
+    tx = x0.flatten()[sel][rep] + local % w[rep]
+    tid = (sel // N)[rep] * (tw * th) + ty * tw + tx
+    dbits = splats[..., 9].contiguous().view(torch.int32).long().flatten() & 0xFFFFFFFF
+    keys = (tid << 32) | dbits[sel][rep]
+    order = torch.sort(keys, stable=True).indices
+    keys, vals = keys[order], sel[rep][order]
+    offs = torch.searchsorted((keys >> 32).contiguous(), torch.arange(C * tw * th, device=dev)).to(torch.int32)
+    return tiles.to(torch.int32), keys, vals.to(torch.int32), offs.reshape(C, th, tw)
