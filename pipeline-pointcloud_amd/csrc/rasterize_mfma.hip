@@ -37,6 +37,15 @@ constexpr int BLOCK = TILE * TILE;
 constexpr int SUB = 32;                       // splats per MFMA sub-batch
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LOG2_MAX_ALPHA = -0.0014434169f;   // log2(0.999)
+constexpr float LOG2_ALPHA_THRESHOLD = -7.99435344f;   // log2(1 / 255)
+
+// 64-bit lane masks straight from a compare (no bool round trip), and back: the wave-uniform bookkeeping of the
+// chain (who is still compositing, who hits this splat, who stops here) lives in SGPR pairs on the scalar unit.
+__device__ __forceinline__ unsigned long long mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3 /* oge */); }
+__device__ __forceinline__ unsigned long long mask_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /* ogt */); }
+__device__ __forceinline__ unsigned long long mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5 /* ole */); }
+__device__ __forceinline__ unsigned long long mask_ge_i(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 39 /* sge */); }
+__device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -59,20 +68,20 @@ __device__ __forceinline__ void quad_coefs(float x, float y, float A, float B, f
 // LDS image of one staged batch of 256 splats
 struct Staged {
     float coef[BLOCK / SUB][6][SUB];     // A operands: [sub-batch][k][row]
-    float4 uni[BLOCK];                   // per splat, wave-uniform in the chain: log2 o, r, g, b
+    float4 uni[BLOCK + 1];               // per splat, wave-uniform in the chain: r, g, b (read one visit ahead)
 };
 
 __device__ __forceinline__ void stage_splat(Staged& L, int slot, bool live, const float* __restrict__ rec_f, float xc,
                                             float yc) {
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
-    float4 u = make_float4(-INFINITY, 0.f, 0.f, 0.f);
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         const float4* rec = reinterpret_cast<const float4*>(rec_f);
         const float4 a = rec[0], bb = rec[1];                 // x y A B | C o r g
         const float cb = rec_f[SP_B];
         if (bb.y > 0.f) {
             quad_coefs(a.x, a.y, a.z, a.w, bb.x, bb.y, xc, yc, c);
-            u = make_float4(__builtin_amdgcn_logf(bb.y), bb.z, bb.w, cb);
+            u = make_float4(bb.z, bb.w, cb, 0.f);
         }
     }
     const int sb = slot >> 5, row = slot & 31;
@@ -147,10 +156,12 @@ __device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane
     }
 }
 
-// alpha of a pair from its log2: min(0.999, o * vis) with sigma clamped at 0 (a PSD form evaluated through
-// the six-term chain can come out a few 1e-5 positive near the splat centre)
-__device__ __forceinline__ float alpha_of(float s, float log2_o) {
-    return __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fminf(s, log2_o), LOG2_MAX_ALPHA));
+// alpha of a pair from its log2: min(0.999, o vis).  (sigma is not clamped at 0: a PSD form evaluated through the
+// six-term chain can come out up to ~3e-4 positive in log2 units at the splat centre, i.e. alpha up to 1.0002 o.)
+// The membership test alpha >= 1/255 is taken in the log domain, on the MFMA result itself: a visit that no lane
+// hits costs ONE vector instruction, and forward and backward can not disagree.
+__device__ __forceinline__ float alpha_of(float s) {
+    return __builtin_amdgcn_exp2f(__builtin_fminf(s, LOG2_MAX_ALPHA));
 }
 
 template <bool HAS_BG>
@@ -176,36 +187,38 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
 
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int cur = 0;
-    bool done = !inside;
+    unsigned long long live = wave_ballot(inside);            // lanes still compositing
     for (int bs = start; bs < end; bs += BLOCK) {
-        if (__syncthreads_count(done) == BLOCK) break;
+        if (!__syncthreads_or(live != 0ull)) break;
         const int idx = bs + (int)threadIdx.x;
-        const bool live = idx < end;
-        stage_splat(L, (int)threadIdx.x, live, splats + (size_t)(live ? flatten_ids[idx] : 0) * SPLAT_STRIDE, xc, yc);
+        const bool in_list = idx < end;
+        stage_splat(L, (int)threadIdx.x, in_list, splats + (size_t)(in_list ? flatten_ids[idx] : 0) * SPLAT_STRIDE, xc, yc);
         __syncthreads();
         const int bsz = min(BLOCK, end - bs);
         for (int sb = 0; sb * SUB < bsz; sb++) {
-            if (wave_ballot(!done) == 0ull) break;
+            if (live == 0ull) break;
             float s[SUB];
             eval_sub_batch(L, sb, lane, basis, s);
+            float4 col_next = L.uni[sb * SUB];
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
-                if ((i & 7) == 0 && i > 0 && wave_ballot(!done) == 0ull) break;
-                const float4 u = L.uni[sb * SUB + i];
-                const float alpha = alpha_of(s[i], u.x);
-                bool ok = !done && alpha >= ALPHA_THRESHOLD;
-                if (wave_ballot(ok) == 0ull) continue;
-                const float wgt0 = ok ? alpha * T : 0.f;
-                const float nT = T - wgt0;                      // T (1 - alpha)
-                const bool stop = ok && nT <= T_STOP;
-                done = done || stop;
-                ok = ok && !stop;
-                const float wgt = ok ? wgt0 : 0.f;
-                cr = __builtin_fmaf(u.y, wgt, cr);
-                cg = __builtin_fmaf(u.z, wgt, cg);
-                cb = __builtin_fmaf(u.w, wgt, cb);
-                cur = ok ? bs + sb * SUB + i : cur;
-                T = ok ? nT : T;
+                if ((i & 7) == 0 && i > 0 && live == 0ull) break;
+                const float4 col = col_next;
+                col_next = L.uni[sb * SUB + i + 1];             // one visit ahead: its latency hides behind this visit
+                const unsigned long long hit = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & live;
+                if (hit == 0ull) continue;
+                const float alpha = alpha_of(s[i]);
+                const float wgt = alpha * T;
+                const float nT = T - wgt;                       // T (1 - alpha)
+                const unsigned long long comp = mask_gt(nT, T_STOP) & hit;      // lanes that composite this splat
+                live &= ~(hit & ~comp);                         // the others that hit it are finished
+                if (lane_of(comp)) {
+                    cr = __builtin_fmaf(col.x, wgt, cr);
+                    cg = __builtin_fmaf(col.y, wgt, cg);
+                    cb = __builtin_fmaf(col.z, wgt, cb);
+                    cur = bs + sb * SUB + i;
+                    T = nT;
+                }
             }
         }
     }
@@ -236,6 +249,61 @@ struct StagedBwd {
     int wave_max[4];
 };
 
+struct PixelBasis { float u, v, uu, uv, vv; };
+
+// One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
+// FAST: every pixel of the wave that composited anything is already in range (index <= its last contributor).
+template <bool ABSGRAD, bool FAST>
+__device__ __forceinline__ void bwd_sub_batch(StagedBwd& L, const float (&s)[SUB], int sb, int be, int lane, int bin_final,
+                                              unsigned long long has, const PixelBasis& px, const float (&vrgb)[3], float tail,
+                                              float& T, float& bufdot) {
+    float4 col_next = L.f.uni[sb * SUB];
+#pragma unroll
+    for (int i = 0; i < SUB; i++) {
+        const int k = sb * SUB + i;
+        const float4 col = col_next;
+        col_next = L.f.uni[k + 1];
+        // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
+        unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
+        if (!FAST) valid &= mask_ge_i(bin_final, be - k);
+        if (valid == 0ull) continue;
+        const float alpha = alpha_of(s[i]);
+        // branch-free live part: a lane that does not take part runs it with alpha = 0 (ra = 1, T and bufdot
+        // unchanged bit for bit, every partial 0)
+        const float a_eff = lane_of(valid) ? alpha : 0.f;
+        const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+        T *= ra;
+        const float fac = a_eff * T;
+        float g_r = fac * vrgb[0], g_g = fac * vrgb[1], g_b = fac * vrgb[2];
+        const float cv = col.x * vrgb[0] + col.y * vrgb[1] + col.z * vrgb[2];            // c . v_rgb
+        const float v_alpha = T * cv - ra * (bufdot - tail);
+        bufdot = __builtin_fmaf(cv, fac, bufdot);
+        // q = o vis dL/dalpha = -dL/dsigma; zero where the 0.999 clamp is active (alpha == o vis otherwise)
+        const unsigned long long gon = valid & mask_le(s[i], LOG2_MAX_ALPHA);
+        float q = lane_of(gon) ? alpha * v_alpha : 0.f;
+        float qu = q * px.u, qv = q * px.v, quu = q * px.uu, quv = q * px.uv, qvv = q * px.vv;
+        float g_ax = 0.f, g_ay = 0.f;
+        if (ABSGRAD) {
+            const float4 ge = L.geo[k];
+            const float cC = L.geo2[k].x;
+            const float dx = ge.x - px.u, dy = ge.y - px.v;
+            g_ax = fabsf(q * (ge.z * dx + ge.w * dy));
+            g_ay = fabsf(q * (ge.w * dx + cC * dy));
+        }
+        // reduce-scatter: lane l ends with the total of value number (l >> 3) in qu, lane 63 with g_b's
+        wave_reduce_scatter8_plus1(qu, qv, quu, quv, qvv, q, g_r, g_g, g_b);
+        if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
+        {
+            const bool last = lane == 63;
+            if ((lane & 7) == 0 || last) atomicAdd(&L.acc[k][last ? AC_B : (lane >> 3)], last ? g_b : qu);
+            if (last) {
+                if (ABSGRAD) { atomicAdd(&L.acc[k][AC_ABSX], g_ax); atomicAdd(&L.acc[k][AC_ABSY], g_ay); }
+                L.touched[k] = 1;
+            }
+        }
+    }
+}
+
 template <bool HAS_BG, bool ABSGRAD>
 __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
@@ -253,8 +321,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     const int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
     const bool inside = px_i < W && py_i < H;
     const float xc = (float)(tx * TILE) + 8.f, yc = (float)(ty * TILE) + 8.f;
-    const float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
-    const float uu = u * u, uv = u * v, vv = v * v;
+    PixelBasis px;
+    px.u = (float)lx - 7.5f; px.v = (float)ly - 7.5f;
+    px.uu = px.u * px.u; px.uv = px.u * px.v; px.vv = px.v * px.v;
     const int start = tile_offsets[t];
     const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
     if (end <= start) return;
@@ -271,6 +340,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         // a pixel that composited nothing has last_id 0 and alpha 0: mark it so that slot `start` is skipped
         if (al == 0.f) bin_final = -1;
     }
+    const float vrgb[3] = {vr0, vr1, vr2};
     float tail = T_final * va;                      // T_final (v_alpha - bg . v_rgb)
     if (HAS_BG) {
         const float* bg = backgrounds + 3 * cam;
@@ -279,6 +349,13 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     int wmax = bin_final;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);            // scalar: the loop bounds and list indices stay on the SALU
+    // smallest last-contributor index among the wave's pixels that composited anything: once the walk is at or
+    // below it, every such pixel is in range and the per-visit index compare drops out (FAST)
+    int wmin = bin_final >= 0 ? bin_final : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o, 64));
+    wmin = __builtin_amdgcn_readfirstlane(wmin);
     if (lane == 0) L.wave_max[wv] = wmax;
     __syncthreads();
     const int bmax = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
@@ -286,7 +363,8 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     const Basis basis = make_basis(wv, lane);
 
     float T = T_final;
-    float buf0 = 0.f, buf1 = 0.f, buf2 = 0.f;
+    float bufdot = 0.f;                         // (colour accumulated behind the current splat) . v_rgb
+    const unsigned long long has = wave_ballot(bin_final >= 0);
     for (int be = bmax; be >= start; be -= BLOCK) {
         // slot k <-> sorted index be - k: rows of a sub-batch run back to front
         const int idx = be - (int)threadIdx.x;
@@ -295,11 +373,11 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         for (int k = 0; k < AC_STRIDE; k++) L.acc[threadIdx.x][k] = 0.f;
         L.touched[threadIdx.x] = 0;
         {
-            const bool live = idx >= start;
-            const int id = live ? flatten_ids[idx] : 0;
+            const bool in_list = idx >= start;
+            const int id = in_list ? flatten_ids[idx] : 0;
             const float* rec_f = splats + (size_t)id * SPLAT_STRIDE;
-            stage_splat(L.f, (int)threadIdx.x, live, rec_f, xc, yc);
-            if (live) {
+            stage_splat(L.f, (int)threadIdx.x, in_list, rec_f, xc, yc);
+            if (in_list) {
                 const float4* rec = reinterpret_cast<const float4*>(rec_f);
                 const float4 a = rec[0], bb = rec[1];
                 L.geo[threadIdx.x] = make_float4(a.x - xc, a.y - yc, a.z, a.w);
@@ -313,49 +391,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         for (int sb = k0 / SUB; sb * SUB < bsz; sb++) {
             float s[SUB];
             eval_sub_batch(L.f, sb, lane, basis, s);
-#pragma unroll
-            for (int i = 0; i < SUB; i++) {
-                const int k = sb * SUB + i;
-                const int sidx = be - k;
-                const float4 un = L.f.uni[k];
-                const float m2 = __builtin_fminf(s[i], un.x);                      // log2 (o vis), sigma clamped at 0
-                const float alpha = __builtin_amdgcn_exp2f(__builtin_fminf(m2, LOG2_MAX_ALPHA));
-                const bool valid = (sidx <= bin_final) && alpha >= ALPHA_THRESHOLD;
-                if (wave_ballot(valid) == 0ull) continue;
-                // branch-free live part: a dead lane runs it with alpha = 0 (ra = 1, T and buf unchanged bit for
-                // bit, every partial 0)
-                const float a_eff = valid ? alpha : 0.f;
-                const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
-                T *= ra;
-                const float fac = a_eff * T;
-                float g_r = fac * vr0, g_g = fac * vr1, g_b = fac * vr2;
-                float v_alpha = (un.y * T - buf0 * ra) * vr0 + (un.z * T - buf1 * ra) * vr1 + (un.w * T - buf2 * ra) * vr2;
-                v_alpha += tail * ra;
-                buf0 += un.y * fac; buf1 += un.z * fac; buf2 += un.w * fac;
-                // q = o vis dL/dalpha = -dL/dsigma; zero where the 0.999 clamp is active (alpha == o vis otherwise)
-                const bool grad_on = valid && m2 <= LOG2_MAX_ALPHA;
-                float q = grad_on ? alpha * v_alpha : 0.f;
-                float qu = q * u, qv = q * v, quu = q * uu, quv = q * uv, qvv = q * vv;
-                float g_ax = 0.f, g_ay = 0.f;
-                if (ABSGRAD) {
-                    const float4 ge = L.geo[k];
-                    const float cC = L.geo2[k].x;
-                    const float dx = ge.x - u, dy = ge.y - v;
-                    g_ax = fabsf(q * (ge.z * dx + ge.w * dy));
-                    g_ay = fabsf(q * (ge.w * dx + cC * dy));
-                }
-                // reduce-scatter: lane l ends with the total of value number (l >> 3) in qu, lane 63 with g_b's
-                wave_reduce_scatter8_plus1(qu, qv, quu, quv, qvv, q, g_r, g_g, g_b);
-                if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
-                {
-                    const bool last = lane == 63;
-                    if ((lane & 7) == 0 || last) atomicAdd(&L.acc[k][last ? AC_B : (lane >> 3)], last ? g_b : qu);
-                    if (last) {
-                        if (ABSGRAD) { atomicAdd(&L.acc[k][AC_ABSX], g_ax); atomicAdd(&L.acc[k][AC_ABSY], g_ay); }
-                        L.touched[k] = 1;
-                    }
-                }
-            }
+            if (be - sb * SUB <= wmin)
+                bwd_sub_batch<ABSGRAD, true>(L, s, sb, be, lane, bin_final, has, px, vrgb, tail, T, bufdot);
+            else
+                bwd_sub_batch<ABSGRAD, false>(L, s, sb, be, lane, bin_final, has, px, vrgb, tail, T, bufdot);
         }
         __syncthreads();
         // flush: lane -> (record = lane >> 4, dword = lane & 15): 4 records = 4 x 64-B requests per instruction.
