@@ -158,7 +158,7 @@ class ViewOrder:
 
 def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int = 100, save_steps=(),
                  on_save=None, strategy: str = "default", cap_max: int = 1_000_000, init_opacity: float = 0.1,
-                 init_scale: float = 1.0) -> Tuple[object, object, Dict]:
+                 init_scale: float = 1.0, frame: str = "nerfstudio") -> Tuple[object, object, Dict]:
     """Loads the dataset, trains, evaluates.  Returns (trainer, dataset, stats)."""
     from . import dataset as ds_mod
     from . import parallel
@@ -169,7 +169,7 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     t0 = time.time()
-    ds = ds_mod.load_colmap_dataset(data_dir, downscale)
+    ds = ds_mod.load_colmap_dataset(data_dir, downscale, frame=frame)
     if callable(cfg):
         cfg = cfg(ds)
     n_pts = ds.points.shape[0]
@@ -238,10 +238,13 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     return tr, ds, stats
 
 
-def world_frame_splats(tr, ds) -> Dict[str, torch.Tensor]:
-    s = tr.model.splats_state_dict()
-    s["means"], s["scales"] = ds.denormalise(s["means"], s["scales"])
-    return s
+def export_frame_splats(tr, ds) -> Dict[str, torch.Tensor]:
+    """The model in the frame the upstream exporters write: the TRAINING frame, as is.  `ns-export
+    gaussian-splat` dumps the model's tensors and `gsplat_pt_to_ply.py:45-73` the checkpoint's, neither maps
+    back to the COLMAP world; the reference's fixed corrections (rotate_splat x:270,y:180,z:0 main.py:1481-1500,
+    mirror x :1510-1523, x:180,y:180 :1556-1592) and its metric-scale stages start from that frame
+    (dataset.py: frame="nerfstudio" is z-up, centred on the cameras, cameras within the unit cube)."""
+    return tr.model.splats_state_dict()
 
 
 # ------------------------------------------------------------------------ entry points
@@ -261,7 +264,7 @@ def main_ns_train(argv: Optional[List[str]] = None) -> int:
     out_dir = os.path.join("outputs", "unnamed", "splatfacto", a["timestamp"])       # the path main.py:2158 copies from
     os.makedirs(os.path.join(out_dir, "nerfstudio_models"), exist_ok=True)
     ckpt = os.path.join(out_dir, "nerfstudio_models", f"step-{cfg.max_steps - 1:09d}.ckpt")
-    io_ply.save_checkpoint(ckpt, world_frame_splats(tr, ds), cfg.max_steps - 1)
+    io_ply.save_checkpoint(ckpt, export_frame_splats(tr, ds), cfg.max_steps - 1)
     with open(os.path.join(out_dir, "config.yml"), "w") as f:
         f.write("# mi3dgs run config (consumed by the ns-export shim)\n")
         f.write(json.dumps(dict(engine="mi3dgs", model=a["model"], data=os.path.abspath(a["data"]),
@@ -299,33 +302,44 @@ def main_ns_export(argv: Optional[List[str]] = None) -> int:
     return 0
 
 
+def _batch_scaled(cfg, batch: int):
+    """The lr / eps / beta part of gsplat's batch-size rule; the step counts are NOT divided again: the
+    reference already passes --steps_scaler 1/G (main.py:1323)."""
+    import dataclasses
+    from . import parallel
+    b = parallel.batch_scaled_config(cfg, batch)
+    return dataclasses.replace(cfg, lr_means=b.lr_means, lr_scales=b.lr_scales, lr_quats=b.lr_quats,
+                               lr_opacities=b.lr_opacities, lr_sh0=b.lr_sh0, lr_shN=b.lr_shN, adam_eps=b.adam_eps,
+                               adam_beta1=b.adam_beta1, adam_beta2=b.adam_beta2)
+
+
 def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
     from . import io_ply, parallel
     if world > 1:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port))
     ctx = parallel.init_from_env() if world > 1 else parallel.DistContext(0, 1, 0)
-    cfg = simple_trainer_config(a, a["max_gaussians"])
-    if world * a["batch_size"] > 1:
-        # the reference already divides the step counts through --steps_scaler 1/G (main.py:1323):
-        # apply only the lr / eps / beta part of gsplat's batch-size rule here
+    cfg0 = simple_trainer_config(a, a["max_gaussians"])
+    bs = world * a["batch_size"]
+
+    def cfg(ds):
         import dataclasses
-        b = parallel.batch_scaled_config(cfg, world * a["batch_size"])
-        cfg = dataclasses.replace(cfg, lr_means=b.lr_means, lr_scales=b.lr_scales, lr_quats=b.lr_quats,
-                                  lr_opacities=b.lr_opacities, lr_sh0=b.lr_sh0, lr_shN=b.lr_shN, adam_eps=b.adam_eps,
-                                  adam_beta1=b.adam_beta1, adam_beta2=b.adam_beta2)
+        c = dataclasses.replace(cfg0, scene_scale=1.1 * ds.scene_scale)      # gsplat: parser.scene_scale * 1.1 * global_scale
+        return _batch_scaled(c, bs) if bs > 1 else c
+
     ck_dir = os.path.join(a["result_dir"], "ckpts")
 
     def save(tr, ds, step):
-        io_ply.save_checkpoint(os.path.join(ck_dir, f"ckpt_{step}_rank{rank}.pt"), world_frame_splats(tr, ds), step)
+        io_ply.save_checkpoint(os.path.join(ck_dir, f"ckpt_{step}_rank{rank}.pt"), export_frame_splats(tr, ds), step)
 
     save_steps = {max(1, int(s * a["steps_scaler"])) for s in (7000, 30000)}
-    tr, ds, stats = run_training(a["data_dir"], a["data_factor"], cfg, ctx=ctx if world > 1 else None,
+    tr, ds, stats = run_training(a["data_dir"], a["data_factor"], cfg, ctx=ctx if world > 1 else None, frame="gsplat",
                                  save_steps=save_steps, on_save=save, strategy=a["strategy"],
                                  cap_max=min(a["max_gaussians"], 1_000_000) if a["strategy"] == "mcmc" else a["max_gaussians"],
                                  # gsplat's `mcmc` preset: init_opa 0.5, init_scale 0.1 [UPSTREAM-UNVERIFIED]
                                  init_opacity=0.5 if a["strategy"] == "mcmc" else 0.1,
                                  init_scale=0.1 if a["strategy"] == "mcmc" else 1.0)
+    cfg = tr.cfg
     save(tr, ds, cfg.max_steps - 1)            # every rank holds the full (replicated) model
     # The reference's exporter converts sorted(os.listdir(ckpts))[-1] (gsplat_pt_to_ply.py:36-40), a
     # LEXICOGRAPHIC sort: with scaled step counts an intermediate "ckpt_874_rank0.pt" sorts after the

@@ -6,9 +6,16 @@ upstream of the hot path, reached by the referen
 
   * layout: D/colmap/sparse/0/*.bin (or D/sparse/0), D/images or D/images_{k} (the reference
     pre-creates the downscaled directory, main.py:419-481);
-  * poses: translated to the centroid of the camera centres and scaled so the farthest camera
-    sits at distance 1 (nerfstudio "center_method=poses" + auto_scale_poses; no re-orientation,
-    the reference re-orients the exported PLY itself, main.py:1481-1500);
+  * world frame = the one the upstream trainer works and EXPORTS in, because the reference's later
+    stages assume it (rotate_splat x:270,y:180,z:0 main.py:1481-1500, mirror x :1510-1523, ...):
+      frame="nerfstudio" (ns-train ... colmap): ColmapDataParser's axis swap (x, z, -y) =
+        `applied_transform`, orientation_method "up" (mean camera up -> +z), center_method "poses"
+        (mean camera position -> origin), auto_scale_poses (largest |camera coordinate| -> 1);
+      frame="gsplat" (simple_trainer.py): the example Parser's normalisation = similarity_from_cameras
+        (mean camera up -> -y, focus point -> origin, median camera distance -> 1) followed by
+        align_principle_axes (PCA of the points);
+      frame="colmap": centre + scale only (round 1; kept for tests that want the raw axes).
+    [UPSTREAM-UNVERIFIED restatements, SURVEY.md 8a row a8]
   * eval split: every 8th image (nerfstudio / gsplat default);
   * Gaussians: means = SfM points, log-scales = log(mean distance to the 3 nearest
     neighbours), random unit quaternions, opacity logit(0.1), SH DC = (rgb - 0.5) / C0,
@@ -41,11 +48,14 @@ class Dataset:
     height: int
     points: torch.Tensor              # [P,3] normalised frame
     points_rgb: torch.Tensor          # [P,3] uint8
-    center: torch.Tensor              # normalisation: x_norm = (x_world - center) * scale
+    center: torch.Tensor              # frame "colmap": x_norm = (x_world - center) * scale
     scale: float
     train_idx: List[int] = field(default_factory=list)
     eval_idx: List[int] = field(default_factory=list)
     undistort: List[Optional[object]] = field(default_factory=list)   # per image: undistort.Plan or None
+    frame: str = "colmap"
+    world_rot: Optional[torch.Tensor] = None      # x_norm = scale * world_rot @ x_world + world_shift   (all frames)
+    world_shift: Optional[torch.Tensor] = None
 
     def load_images(self, idx: List[int], device, as_u8: bool = False) -> torch.Tensor:
         """[len(idx),H,W,3] on `device`: float32 in [0,1], or uint8 (`as_u8`, the device image
@@ -80,13 +90,86 @@ class Dataset:
         return out
 
     def denormalise(self, means: torch.Tensor, log_scales: torch.Tensor):
-        """Normalised frame -> the COLMAP world frame of the input (for export)."""
+        """Normalised frame -> the COLMAP world frame of the input.  Positions and sizes only: valid as a whole
+        for frame="colmap" (no rotation); the upstream exporters do NOT do this, they write the training frame."""
+        if self.world_rot is not None and not torch.equal(self.world_rot, torch.eye(3)):
+            raise ValueError("denormalise() is for the un-rotated 'colmap' frame; rotate with mi3dgs.transform instead")
         c = self.center.to(means.device, means.dtype)
         return means / self.scale + c, log_scales - math.log(self.scale)
 
+    @property
+    def scene_scale(self) -> float:
+        """gsplat Parser.scene_scale: largest distance of a camera from the mean camera position."""
+        c2w = torch.linalg.inv(self.viewmats.double())
+        pos = c2w[:, :3, 3]
+        return float((pos - pos.mean(0)).norm(dim=1).max())
+
+
+APPLIED_TRANSFORM = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]])   # ColmapDataParser: (x, z, -y)
+
+
+def rotation_matrix_between(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nerfstudio camera_utils.rotation_matrix_between: the rotation about a x b that takes a to b (Rodrigues)."""
+    a, b = a / np.linalg.norm(a), b / np.linalg.norm(b)
+    v = np.cross(a, b)
+    eps = 1e-6
+    if np.abs(v).sum() < eps:
+        x = np.array([1.0, 0.0, 0.0]) if abs(a[0]) < eps else np.array([0.0, 1.0, 0.0])
+        v = np.cross(a, x)
+    v = v / np.linalg.norm(v)
+    K = np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+    theta = math.acos(float(np.clip(np.dot(a, b), -1.0, 1.0)))
+    return np.eye(3) + math.sin(theta) * K + (1.0 - math.cos(theta)) * (K @ K)
+
+
+def nerfstudio_frame(c2w_cv: np.ndarray):
+    """(s, Q, t) with x_n = s Q x_w + t: ColmapDataParser + auto_orient_and_center_poses("up", "poses") +
+    auto_scale_poses, from OpenCV camera-to-world matrices [V,4,4].  [UPSTREAM-UNVERIFIED]"""
+    P = APPLIED_TRANSFORM
+    up_gl = -c2w_cv[:, :3, 1]                          # OpenGL camera +y (up) = minus OpenCV +y (down)
+    up = (P @ up_gl.T).T.mean(0)
+    up = up / np.linalg.norm(up)
+    Rot = rotation_matrix_between(up, np.array([0.0, 0.0, 1.0]))
+    origins = (P @ c2w_cv[:, :3, 3].T).T
+    mean_o = origins.mean(0)
+    pos = (Rot @ (origins - mean_o).T).T
+    s = 1.0 / max(float(np.abs(pos).max()), 1e-9)
+    Q = Rot @ P
+    return s, Q, -s * (Rot @ mean_o)
+
+
+def gsplat_frame(c2w_cv: np.ndarray, points: np.ndarray):
+    """(s, Q, t) of gsplat's examples/datasets Parser(normalize=True): similarity_from_cameras (mean camera up
+    -> -y, median closest point of the optical axes to the origin -> origin, median camera distance -> 1), then
+    align_principle_axes on the transformed points (PCA, largest variance on x).  [UPSTREAM-UNVERIFIED]"""
+    t, R = c2w_cv[:, :3, 3], c2w_cv[:, :3, :3]
+    ups = (R * np.array([0.0, -1.0, 0.0])).sum(-1)
+    world_up = ups.mean(0)
+    world_up = world_up / np.linalg.norm(world_up)
+    up_cam = np.array([0.0, -1.0, 0.0])
+    c = float((up_cam * world_up).sum())
+    cr = np.cross(world_up, up_cam)
+    skew = np.array([[0.0, -cr[2], cr[1]], [cr[2], 0.0, -cr[0]], [-cr[1], cr[0], 0.0]])
+    R_align = np.eye(3) + skew + (skew @ skew) / (1.0 + c) if c > -1 else np.diag([-1.0, 1.0, 1.0])
+    Rr = R_align @ R
+    fwds = (Rr * np.array([0.0, 0.0, 1.0])).sum(-1)
+    tt = (R_align @ t.T).T
+    nearest = tt + (fwds * -tt).sum(-1)[:, None] * fwds
+    translate = -np.median(nearest, axis=0)
+    s = 1.0 / max(float(np.median(np.linalg.norm(tt + translate, axis=-1))), 1e-9)
+    Q1, t1 = R_align, s * translate                      # x1 = s (R_align x + translate)
+    p1 = s * (Q1 @ points.T).T + t1
+    centroid = np.median(p1, axis=0)
+    w, v = np.linalg.eigh(np.cov(p1 - centroid, rowvar=False))
+    v = v[:, w.argsort()[::-1]]
+    if np.linalg.det(v) < 0:
+        v[:, 0] *= -1
+    R2 = v.T
+    return s, R2 @ Q1, R2 @ t1 - R2 @ centroid
+
 
 def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: int = 8,
-                        normalize: bool = True, undistort: bool = True) -> Dataset:
+                        normalize: bool = True, undistort: bool = True, frame: str = "colmap") -> Dataset:
     sparse = io_colmap.find_sparse_dir(data_dir)
     cams = io_colmap.read_cameras(os.path.join(sparse, "cameras.bin"))
     imgs = io_colmap.read_images(os.path.join(sparse, "images.bin"))
@@ -102,16 +185,26 @@ def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: in
     w2c = np.stack([im.world_to_camera() for im in items])                  # [V,4,4]
     c2w = np.linalg.inv(w2c)
     centres = c2w[:, :3, 3]
+    if frame not in ("colmap", "nerfstudio", "gsplat"):
+        raise ValueError(f"unknown world frame {frame!r}")
     center = centres.mean(0) if normalize else np.zeros(3)
-    scale = 1.0
-    if normalize:
+    scale, Q = 1.0, np.eye(3)
+    if normalize and frame == "colmap":
         scale = 1.0 / max(float(np.abs(centres - center).max()), 1e-9)
-    # x_n = (x_w - center) * scale  =>  camera = R x_w + t = R (x_n / scale + center) + t ; keep metric
-    # camera space scaled by `scale` as well so depths shrink with the scene: t_n = (R center + t) * scale
+        shift = -scale * center
+    elif normalize and frame == "nerfstudio":
+        scale, Q, shift = nerfstudio_frame(c2w)
+    elif normalize:
+        scale, Q, shift = gsplat_frame(c2w, np.asarray(xyz, dtype=np.float64))
+    else:
+        shift = np.zeros(3)
+    # x_n = s Q x_w + shift  =>  x_c = R x_w + t = R Q^T (x_n - shift) / s + t.  Camera space is scaled by s as
+    # well, so depths shrink with the scene:  s x_c = (R Q^T) x_n + (s t - R Q^T shift)
     R = w2c[:, :3, :3]
-    t_n = (np.einsum("vij,j->vi", R, center) + w2c[:, :3, 3]) * scale
+    Rn = np.einsum("vij,kj->vik", R, Q)
+    t_n = scale * w2c[:, :3, 3] - np.einsum("vij,j->vi", Rn, shift)
     vm = np.tile(np.eye(4), (len(items), 1, 1))
-    vm[:, :3, :3] = R
+    vm[:, :3, :3] = Rn
     vm[:, :3, 3] = t_n
     Ks, dist_warn, plans, plan_of = [], False, [], {}
     cam0 = cams[items[0].camera_id]
@@ -142,11 +235,12 @@ def load_colmap_dataset(data_dir: str, downscale_factor: int = 1, test_every: in
     V = len(items)
     eval_idx = [i for i in range(V) if test_every > 0 and i % test_every == 0]
     train_idx = [i for i in range(V) if i not in set(eval_idx)] or list(range(V))
-    pts = (xyz - center) * scale
+    pts = scale * (np.asarray(xyz, dtype=np.float64) @ Q.T) + shift
     return Dataset(torch.from_numpy(vm).float(), torch.tensor(Ks, dtype=torch.float32),
                    [os.path.join(img_dir, im.name) for im in items], [im.name for im in items], W, H,
                    torch.from_numpy(pts).float(), torch.from_numpy(rgb.copy()), torch.from_numpy(center).float(),
-                   float(scale), train_idx, eval_idx, plans)
+                   float(scale), train_idx, eval_idx, plans, frame if normalize else "colmap",
+                   torch.from_numpy(Q).float(), torch.from_numpy(np.asarray(shift)).float())
 
 
 def knn_mean_sq_dist(points: torch.Tensor, k: int = 3) -> torch.Tensor:
