@@ -116,7 +116,10 @@ size_t mi3dgs_bin_workspace_bytes(int C, int N, long long max_isect);
  * isect_ids, tiles_per_gauss identical to upstream).  `tight` = 1: per tile row keep only the
  * span the ellipse sigma <= ln(255 opacity) reaches -- renders and gradients are bit-identical
  * (the dropped pairs fail the rasteriser's alpha >= 1/255 test on every pixel), the lists are
- * shorter.  `height` is the image height in pixels.  Both phases must use the same value. */
+ * shorter.  `height` is the image height in pixels.  Both phases must use the same value.
+ * `tight` is a bit field: bit 0 as above; bit 1 (value 2) = the splat records carry their integer radii in
+ * slots 11 and 12 (mi3dgs_project_fwd writes them there), so the emit pass gathers ONE line per splat instead of
+ * a record plus an 8-byte radii entry from a second random sector.  Leave it clear for hand-made records. */
 int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float* splats, int tile_size,
                      int tile_width, int tile_height, int height, int tight,
                      int32_t* tiles_per_gauss /* [C*N], nullable */, int32_t* n_isect_dev /* [1] */,
@@ -218,11 +221,13 @@ int mi3dgs_densify_decide(int N, const float* scales_log, const float* opacities
                           float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs,
                           int do_grow, int check_too_big, uint8_t* flags, uint32_t* out_count,
                           void* stream);
-int mi3dgs_densify_scatter(int N, const float* const* params_in, const float* const* exp_avg_in,
-                           const float* const* exp_avg_sq_in, float* const* params_out,
-                           float* const* exp_avg_out, float* const* exp_avg_sq_out,
-                           const uint8_t* flags, const uint32_t* offsets, long long capacity,
-                           uint32_t seed, void* stream);
+/* n_out = the scan's total (the caller has read it back to size / swap its buffers anyway);
+ * map_workspace[capacity] u32: for every output row, where it comes from (a row-gather per array follows). */
+int mi3dgs_densify_scatter(int N, long long n_out, const float* const* params_in,
+                           const float* const* exp_avg_in, const float* const* exp_avg_sq_in,
+                           float* const* params_out, float* const* exp_avg_out,
+                           float* const* exp_avg_sq_out, const uint8_t* flags, const uint32_t* offsets,
+                           long long capacity, uint32_t seed, uint32_t* map_workspace, void* stream);
 int mi3dgs_reset_opacity(int N, float* opacities_logit, float max_logit, float* exp_avg,
                          float* exp_avg_sq, void* stream);
 

@@ -353,9 +353,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 constexpr int OS_MAX_PASSES = 4;
 constexpr unsigned OS_SPIN_LIMIT = CHAIN_SPIN_LIMIT;
 
+// DROP: keys equal to 0xFFFFFFFF (the depth sort's "culled" sentinel) are not counted; the number of the others
+// goes to *n_live_out, and pass 0 (os_pass_kernel<DROP>) leaves them behind, so the later passes -- and
+// everything downstream of the sort -- work on the visible splats only.
+template <bool DROP>
 __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap, int passes,
-                                                             int per, int nbits, uint32_t* __restrict__ ghist /*[passes][256]*/) {
+                                                             int per, int nbits, uint32_t* __restrict__ ghist /*[passes][256]*/,
+                                                             uint32_t* __restrict__ n_live_out) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     uint32_t n = live_count(n_ptr, cap);
     uint32_t base = blockIdx.x * OS_TILE;
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __r
         uint32_t idx = base + i * RS_THREADS + threadIdx.x;
         if (idx < n) {
             uint32_t k = keys[idx];
+            if (DROP && k == 0xFFFFFFFFu) continue;
             int shift = 0;
             for (int p = 0; p < passes; p++) {
                 int bits = (shift + per <= nbits) ? per : (nbits - shift);
@@ -381,12 +387,19 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __r
         uint32_t c = h[p][threadIdx.x];
         if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
     }
+    if (DROP) {
+        // the block's live keys = the sum of any one pass's counters
+        uint32_t tot;
+        block_excl_scan_u32(h[0][threadIdx.x], &tot, h[1]);
+        if (threadIdx.x == 0 && tot) atomicAdd(n_live_out, tot);
+    }
 }
 
 __device__ __forceinline__ unsigned long long os_pack(uint32_t epoch, uint32_t flag, uint32_t value) {
     return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned long long)value;
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
-        bool valid = idx < n;
+        bool valid = idx < n && !(DROP && key[r] == 0xFFFFFFFFu);
         uint32_t k = key[r];
         uint32_t d = (k >> shift) & mask;
         unsigned long long peers = wave_ballot(valid);
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
-        if (idx < n) {
+        if (idx < n && !(DROP && key[r] == 0xFFFFFFFFu)) {
             uint32_t d = (key[r] >> shift) & mask;
             uint32_t slot = cnt[w][d] + loc[r];
             skey[slot] = key[r];
@@ -491,6 +504,8 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         vals_out[pos] = sval[j];
     }
 }
+
+__global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 
 // 0 = classic (histogram + 3-kernel scan + scatter per pass), 1 = onesweep, 2 = by size (default).
 // Measured on MI355X: onesweep wins while the sort is launch-latency bound (2 M keys, 4 passes:
@@ -513,7 +528,10 @@ size_t rs_tmp_u32(uint32_t cap) {
 // if the number of passes is even, else in (keys_b, vals_b); returns via *result_in_b.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr,
                      uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what = "sort",
-                     bool identity_vals = false) {
+                     bool identity_vals = false, uint32_t* n_live_out = nullptr) {
+    // n_live_out (device word; n_ptr must be null): keys equal to 0xFFFFFFFF are sentinels.  Onesweep path: they are
+    // dropped in pass 0, *n_live_out receives the number of real keys and only those come out (sorted) at the head
+    // of the result.  Classic path (large sorts): nothing is dropped, *n_live_out = cap (the sentinels sort last).
     // profiler tags carry the caller's name so the 2M-key depth sort and the I-key tile sort stay apart
     static thread_local char htag_buf[48], ctag_buf[48], s0[48];
     snprintf(htag_buf, sizeof(htag_buf), "rs_hist/%s", what);
@@ -539,12 +557,22 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         unsigned long long* status = reinterpret_cast<unsigned long long*>(tmp + OS_MAX_PASSES * 256 + 16);
         // one clear per sort call: histograms, counters, and the status table (epochs 1..passes)
         MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B) * sizeof(uint32_t), st));
-        MI_LAUNCH(htag, os_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist);
+        if (n_live_out) {
+            MI_REQUIRE(!n_ptr, "sort: sentinel dropping needs a host-known input size");
+            MI_HIP(hipMemsetAsync(n_live_out, 0, sizeof(uint32_t), st));
+            MI_LAUNCH(htag, os_hist_kernel<true>, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+        } else {
+            MI_LAUNCH(htag, os_hist_kernel<false>, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+        }
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
-            MI_LAUNCH(ctag, os_pass_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
-                      ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
+            if (n_live_out && p == 0)
+                MI_LAUNCH(ctag, os_pass_kernel<true>, dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
+                          ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
+            else
+                MI_LAUNCH(ctag, os_pass_kernel<false>, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
+                          n_live_out ? n_live_out : n_ptr, cap, shift, mask, ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
@@ -554,6 +582,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         *result_in_b = passes & 1;
         return 0;
     }
+    if (n_live_out) MI_LAUNCH("set_u32", set_u32_kernel, dim3(1), dim3(1), 0, st, n_live_out, cap);
     uint32_t* hist = tmp;
     uint32_t* scan_tmp = tmp + (size_t)256 * B;
     for (int p = 0; p < passes; p++) {
@@ -773,7 +802,8 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(uint32_t CN, const int3
 // three-kernel scan (and the second row-table build) disappear.  The last block leaves the
 // total in *n_isect_out.
 template <bool TIGHT, bool CHAINED>
-__global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N, const uint32_t* __restrict__ sorted_ids,
+__global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN_cap, const uint32_t* __restrict__ n_sorted_ptr, bool radii_in_records,
+                                                        uint32_t N, const uint32_t* __restrict__ sorted_ids,
                                                         const uint32_t* __restrict__ cum,
                                                         const int32_t* __restrict__ radii,
                                                         const float* __restrict__ splats, int tile_size, int tw, int th,
@@ -796,6 +826,10 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
         __syncthreads();
         blk = s_blk;
     }
+    // the sorted list may be shorter than its capacity (the depth sort dropped the culled splats); blocks past
+    // its end have nothing to do, and nobody waits on them: block ids are handed out in order
+    const uint32_t CN = live_count(n_sorted_ptr, CN_cap);
+    if (blk * blockDim.x >= CN) return;
     uint32_t i = blk * blockDim.x + threadIdx.x;
     uint32_t my_cum = 0, my_n = 0, idx = 0, key0 = 0;
     int w = 1;
@@ -803,10 +837,13 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
     if (i < CN) {
         idx = sorted_ids[i];
         if (!CHAINED) my_cum = cum[i];
-        int2 r = *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
+        const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
+        // ONE gather per splat when the radii travel inside the record (project_fwd writes them there); the
+        // separate radii array costs a second random 64-byte sector per splat for 8 bytes
+        int2 r = radii_in_records ? make_int2(__float_as_int(sp[SP_RX]), __float_as_int(sp[SP_RY]))
+                                  : *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
         if (r.x > 0 && r.y > 0) {
             vis = true;
-            const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
             if (TIGHT) {
                 s_geo[threadIdx.x] = span_geom(sp, r, tile_size, tw, th);
                 key0 = (idx / N) * (uint32_t)(tw * th);
@@ -832,7 +869,7 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN, uint32_t N,
             uint32_t excl = chain_lookback(status, blk, total, (int)threadIdx.x, chain_err);
             if (threadIdx.x == 0) {
                 s_base = excl;
-                if (blk == gridDim.x - 1) {
+                if (blk == (CN - 1) / blockDim.x) {
                     // the count every later kernel (sort, offsets, rasterisers) reads is clamped to the
                     // capacity of the buffers; an overflow is reported through the sticky error word (bit 2)
                     uint32_t tot = excl + total;
@@ -1070,6 +1107,7 @@ extern "C" int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float*
     BinWs ws;
     size_t need = bin_ws_layout(CN, (uint32_t)max_isect, (uint32_t*)workspace, &ws);
     MI_REQUIRE(workspace && workspace_bytes >= need, "bin_count: workspace too small");
+    tight &= MI_BIN_TIGHT;
     if (tight)
         MI_LAUNCH("tile_count", tile_count_kernel<true>, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats,
                   tile_size, tile_width, tile_height, height, ws.tiles, ws.dkeys_a, ws.ids_a);
@@ -1139,15 +1177,17 @@ extern "C" int mi3dgs_bin_emit(int C, int N, const int32_t* radii, const float* 
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     uint32_t* slow_count = ws.n_isect + 4;
+    const bool rir = (tight & MI_BIN_RADII_IN_RECORDS) != 0;
+    tight &= MI_BIN_TIGHT;
     if (tight) {
         MI_HIP(hipMemsetAsync(slow_count, 0, 4, st));
-        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, nullptr, rir, (uint32_t)N, ws.ids_a,
                   ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
                   nullptr, nullptr, nullptr, ws.slow, slow_count);
         MI_LAUNCH("tile_emit_slow", tile_emit_slow_kernel, dim3(SLOW_BLOCKS), dim3(256), 0, st, ws.slow, slow_count, tile_size,
                   tile_width, height, cap, tk, fi);
     } else {
-        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, (uint32_t)N, ws.ids_a,
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, false>), dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, nullptr, rir, (uint32_t)N, ws.ids_a,
                   ws.cum, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, nullptr, nullptr,
                   nullptr, nullptr, nullptr, nullptr, nullptr);
     }
@@ -1187,9 +1227,15 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     if (!depth_keys_opt)
         MI_LAUNCH("depth_keys", depth_keys_kernel, dim3(mi_div_up(CN, 256)), dim3(256), 0, st, CN, radii, splats, dkeys,
                   ws.ids_a);
+    // the depth sort leaves the culled splats (key 0xFFFFFFFF) behind: everything after it walks the visible ones only
+    const bool rir = (tight & MI_BIN_RADII_IN_RECORDS) != 0;
+    tight &= MI_BIN_TIGHT;
+    uint32_t* n_live = ws.n_isect + 8;
+    MI_HIP(hipMemsetAsync(n_isect_dev, 0, 4, st));
+    if (tiles_per_gauss_opt) MI_HIP(hipMemsetAsync(tiles_per_gauss_opt, 0, (size_t)CN * 4, st));
     int in_b = 0;
     int rc = radix_sort_pairs(dkeys, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth",
-                              /*identity_vals=*/depth_keys_opt != nullptr);
+                              /*identity_vals=*/depth_keys_opt != nullptr, n_live);
     if (rc) return rc;
     const uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
     // chain state lives in the (unused here) `cum` array: status[nblocks] u64 | counter | err
@@ -1203,11 +1249,11 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     if (tight)
-        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, ws.slow, slow_count);
     else
-        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, CN, (uint32_t)N, sorted_ids,
+        MI_LAUNCH("tile_emit", (tile_emit_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, nullptr, nullptr);
     if (tight)

@@ -19,6 +19,8 @@
 #define SP_B 8
 #define SP_DEPTH 9
 #define SP_COMP 10
+#define SP_RX 11       // the integer radii (bit patterns), so that the binning needs ONE gather per splat
+#define SP_RY 12
 
 // ---- gradient record: one 64-byte line per (camera, Gaussian), accumulated by
 // rasterize_bwd with float atomics (one 64-B atomic request per (tile, Gaussian)).
@@ -39,6 +41,8 @@
 #define MI_FLAG_LOG_SCALES 1      // scales are log-space parameters (exp applied in-kernel)
 #define MI_FLAG_LOGIT_OPAC 2      // opacities are logits (sigmoid applied in-kernel)
 #define MI_FLAG_ANTIALIASED 4     // rasterize_mode == "antialiased": opacity *= compensation
+#define MI_BIN_TIGHT 1             // mi3dgs_bin_*: `tight` argument, bit 0 = exact ellipse culling
+#define MI_BIN_RADII_IN_RECORDS 2  //   bit 1 = take the radii from record slots SP_RX / SP_RY (written by project_fwd)
 #define MI_FLAG_PROBE 16          // project_bwd_adam: same code under another kernel name (placement search)
 
 #define ALPHA_THRESHOLD (1.0f / 255.0f)

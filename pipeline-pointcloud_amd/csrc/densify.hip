@@ -65,26 +65,19 @@ __global__ __launch_bounds__(256) void densify_decide_kernel(
     out_count[n] = prune ? 0u : ((dup || split) ? 2u : 1u);
 }
 
-struct DensifyBufs {
-    const float* in[6];     // means, quats, scales, opacities, sh0, shN
-    const float* in_m[6];
-    const float* in_v[6];
-    float* out[6];
-    float* out_m[6];
-    float* out_v[6];
-};
+// ---- scatter = map + row gathers.  A first version copied rows one thread per Gaussian (45 floats at a
+// 180-byte stride per lane): 3.4 ms for 2 M Gaussians, 1.1 TB/s.  Now a map pass writes, for every OUTPUT row,
+// where it comes from; then each of the 18 arrays is rebuilt by a flat gather whose consecutive threads
+// store consecutive 16-byte pieces of the output and read (almost always) consecutive pieces of the input,
+// because survivors keep their order.
+constexpr uint32_t MAP_ZERO_STATE = 1u << 31;     // the copy starts with zero Adam moments
+constexpr uint32_t MAP_SPLIT = 1u << 30;          // position re-sampled, scale / 1.6
+constexpr uint32_t MAP_SECOND = 1u << 29;         // second child (its own random sample)
+constexpr uint32_t MAP_INDEX = (1u << 29) - 1u;
 
-__device__ __forceinline__ void copy_row(const float* __restrict__ src, float* __restrict__ dst, int w) {
-    for (int i = 0; i < w; i++) dst[i] = src[i];
-}
-__device__ __forceinline__ void zero_row(float* __restrict__ dst, int w) {
-    for (int i = 0; i < w; i++) dst[i] = 0.f;
-}
-
-__global__ __launch_bounds__(256) void densify_scatter_kernel(int N, DensifyBufs b, const uint8_t* __restrict__ flags,
-                                                              const uint32_t* __restrict__ offsets, uint32_t cap,
-                                                              uint32_t seed) {
-    const int widths[6] = {3, 4, 3, 1, 3, 45};
+__global__ __launch_bounds__(256) void densify_map_kernel(int N, const uint8_t* __restrict__ flags,
+                                                          const uint32_t* __restrict__ offsets, uint32_t cap,
+                                                          uint32_t* __restrict__ src_of) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     uint8_t f = flags[n];
@@ -93,45 +86,74 @@ __global__ __launch_bounds__(256) void densify_scatter_kernel(int N, DensifyBufs
     bool dup = f & 1, split = f & 2;
     int copies = (dup || split) ? 2 : 1;
     if (o + copies > cap) return;   // capacity guard; the host checks the total first
-    for (int c = 0; c < copies; c++) {
-        bool keep_state = !split && c == 0;
-        for (int g = 0; g < 6; g++) {
-            int w = widths[g];
-            const float* src = b.in[g] + (size_t)n * w;
-            float* dst = b.out[g] + (size_t)(o + c) * w;
-            copy_row(src, dst, w);
-            float* dm = b.out_m[g] + (size_t)(o + c) * w;
-            float* dv = b.out_v[g] + (size_t)(o + c) * w;
-            if (keep_state) {
-                copy_row(b.in_m[g] + (size_t)n * w, dm, w);
-                copy_row(b.in_v[g] + (size_t)n * w, dv, w);
-            } else {
-                zero_row(dm, w);
-                zero_row(dv, w);
-            }
-        }
-        if (split) {
-            // sample = R(q) * (exp(s) .* randn(3)); mean += sample; s = log(exp(s) / 1.6)
-            const float* q = b.in[1] + (size_t)n * 4;
-            float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-            float inv = rsqrtf(fmaxf(n2, 1e-24f));
-            float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
-            float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
-                          2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
-                          2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
-            const float* sl = b.in[2] + (size_t)n * 3;
-            float r0, r1, r2, r3;
-            randn2(seed, (uint32_t)n * 4u + (uint32_t)c * 2u, r0, r1);
-            randn2(seed, (uint32_t)n * 4u + (uint32_t)c * 2u + 1u, r2, r3);
-            float e[3] = {__expf(sl[0]) * r0, __expf(sl[1]) * r1, __expf(sl[2]) * r2};
-            float* mo = b.out[0] + (size_t)(o + c) * 3;
-            float* so = b.out[2] + (size_t)(o + c) * 3;
-            for (int i = 0; i < 3; i++) {
-                mo[i] += R[3 * i] * e[0] + R[3 * i + 1] * e[1] + R[3 * i + 2] * e[2];
-                so[i] = sl[i] - 0.47000362924573563f;   // log(1.6)
-            }
+    for (int c = 0; c < copies; c++)
+        src_of[o + c] = (uint32_t)n | ((split || c > 0) ? MAP_ZERO_STATE : 0u) | (split ? MAP_SPLIT : 0u) | (c ? MAP_SECOND : 0u);
+}
+
+// out[o][0..W) = in[src_of[o]][0..W), or zeros for a moment array of a fresh copy; 4 floats per thread
+template <int W, bool MOMENT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(long long n_floats, const float* __restrict__ in,
+                                                          float* __restrict__ out, const uint32_t* __restrict__ src_of) {
+    long long e0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e0 >= n_floats) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        long long e = e0 + j;
+        v[j] = 0.f;
+        if (e < n_floats) {
+            uint32_t o = (uint32_t)(e / W);
+            uint32_t c = (uint32_t)(e - (long long)o * W);
+            uint32_t m = src_of[o];
+            if (!(MOMENT && (m & MAP_ZERO_STATE))) v[j] = in[(size_t)(m & MAP_INDEX) * W + c];
         }
     }
+    if (e0 + 4 <= n_floats) *reinterpret_cast<float4*>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+        for (int j = 0; j < 4 && e0 + j < n_floats; j++) out[e0 + j] = v[j];
+}
+
+// the two children of a split Gaussian: mean += R(q) (exp(s) .* randn(3)), s = log(exp(s) / 1.6)
+__global__ __launch_bounds__(256) void densify_split_kernel(uint32_t n_out, const uint32_t* __restrict__ src_of,
+                                                            const float* __restrict__ quats_in,
+                                                            const float* __restrict__ scales_in,
+                                                            float* __restrict__ means_out, float* __restrict__ scales_out,
+                                                            uint32_t seed) {
+    uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    uint32_t m = src_of[o];
+    if (!(m & MAP_SPLIT)) return;
+    uint32_t n = m & MAP_INDEX, c = (m & MAP_SECOND) ? 1u : 0u;
+    const float* q = quats_in + (size_t)n * 4;
+    float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    float inv = rsqrtf(fmaxf(n2, 1e-24f));
+    float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    float R[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - w * z), 2.f * (x * z + w * y),
+                  2.f * (x * y + w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - w * x),
+                  2.f * (x * z - w * y), 2.f * (y * z + w * x), 1.f - 2.f * (x * x + y * y)};
+    const float* sl = scales_in + (size_t)n * 3;
+    float r0, r1, r2, r3;
+    randn2(seed, n * 4u + c * 2u, r0, r1);
+    randn2(seed, n * 4u + c * 2u + 1u, r2, r3);
+    float e[3] = {__expf(sl[0]) * r0, __expf(sl[1]) * r1, __expf(sl[2]) * r2};
+    float* mo = means_out + (size_t)o * 3;
+    float* so = scales_out + (size_t)o * 3;
+    for (int i = 0; i < 3; i++) {
+        mo[i] += R[3 * i] * e[0] + R[3 * i + 1] * e[1] + R[3 * i + 2] * e[2];
+        so[i] = sl[i] - 0.47000362924573563f;   // log(1.6)
+    }
+}
+
+template <int W>
+int gather_group(long long n_out, const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out,
+                 float* v_out, const uint32_t* src_of, hipStream_t st) {
+    long long nf = n_out * W;
+    dim3 grid((unsigned)mi_div_up(mi_div_up(nf, 4), 256));
+    MI_LAUNCH("densify_gather", (gather_rows_kernel<W, false>), grid, dim3(256), 0, st, nf, p_in, p_out, src_of);
+    MI_LAUNCH("densify_gather", (gather_rows_kernel<W, true>), grid, dim3(256), 0, st, nf, m_in, m_out, src_of);
+    MI_LAUNCH("densify_gather", (gather_rows_kernel<W, true>), grid, dim3(256), 0, st, nf, v_in, v_out, src_of);
+    MI_LAUNCH_CHECK();
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void reset_opacity_kernel(int N, float* __restrict__ opac_logit, float max_logit,
@@ -159,23 +181,30 @@ extern "C" int mi3dgs_densify_decide(int N, const float* scales_log, const float
     return 0;
 }
 
-// Step 2 (after mi3dgs_scan_exclusive_u32 over out_count): scatter parameters and Adam
-// moments of the 6 groups {means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45]}
-// into fresh buffers of `capacity` Gaussians.
-extern "C" int mi3dgs_densify_scatter(int N, const float* const* params_in, const float* const* exp_avg_in,
+// Step 2 (after mi3dgs_scan_exclusive_u32 over out_count, whose total `n_out` the host has read back):
+// rebuild parameters and Adam moments of the 6 groups {means[3], quats[4], scales[3], opacities[1], sh0[3],
+// shN[45]} in fresh buffers.  map_workspace: `capacity` u32.
+extern "C" int mi3dgs_densify_scatter(int N, long long n_out, const float* const* params_in, const float* const* exp_avg_in,
                                       const float* const* exp_avg_sq_in, float* const* params_out,
                                       float* const* exp_avg_out, float* const* exp_avg_sq_out, const uint8_t* flags,
-                                      const uint32_t* offsets, long long capacity, uint32_t seed, void* stream) {
-    if (N <= 0) return 0;
-    DensifyBufs b;
-    for (int g = 0; g < 6; g++) {
-        b.in[g] = params_in[g]; b.in_m[g] = exp_avg_in[g]; b.in_v[g] = exp_avg_sq_in[g];
-        b.out[g] = params_out[g]; b.out_m[g] = exp_avg_out[g]; b.out_v[g] = exp_avg_sq_out[g];
-        MI_REQUIRE(b.in[g] && b.in_m[g] && b.in_v[g] && b.out[g] && b.out_m[g] && b.out_v[g],
+                                      const uint32_t* offsets, long long capacity, uint32_t seed, uint32_t* map_workspace,
+                                      void* stream) {
+    if (N <= 0 || n_out <= 0) return 0;
+    MI_REQUIRE(n_out <= capacity && capacity <= (long long)MAP_INDEX, "densify_scatter: n_out exceeds the capacity");
+    MI_REQUIRE(map_workspace, "densify_scatter: null map workspace");
+    for (int g = 0; g < 6; g++)
+        MI_REQUIRE(params_in[g] && exp_avg_in[g] && exp_avg_sq_in[g] && params_out[g] && exp_avg_out[g] && exp_avg_sq_out[g],
                    "densify_scatter: null buffer");
-    }
-    MI_LAUNCH("densify_scatter", densify_scatter_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, b, flags,
-                       offsets, (uint32_t)capacity, seed);
+    hipStream_t st = (hipStream_t)stream;
+    MI_LAUNCH("densify_map", densify_map_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, st, N, flags, offsets,
+              (uint32_t)capacity, map_workspace);
+    int rc = 0;
+#define GG(g, W) rc = rc ? rc : gather_group<W>(n_out, params_in[g], exp_avg_in[g], exp_avg_sq_in[g], params_out[g], exp_avg_out[g], exp_avg_sq_out[g], map_workspace, st)
+    GG(0, 3); GG(1, 4); GG(2, 3); GG(3, 1); GG(4, 3); GG(5, 45);
+#undef GG
+    if (rc) return rc;
+    MI_LAUNCH("densify_split", densify_split_kernel, dim3(mi_div_up(n_out, 256)), dim3(256), 0, st, (uint32_t)n_out, map_workspace,
+              params_in[1], params_in[2], params_out[0], params_out[2], seed);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     *rad = make_int2((int)rx, (int)ry);
     rec[0] = make_float4(P.m2x, P.m2y, P.conA, P.conB);
     rec[1] = make_float4(P.conC, opa, rgb[0], rgb[1]);
-    rec[2] = make_float4(rgb[2], P.mc[2], P.comp, 0.f);
-    rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rec[2] = make_float4(rgb[2], P.mc[2], P.comp, __int_as_float((int)rx));
+    rec[3] = make_float4(__int_as_float((int)ry), 0.f, 0.f, 0.f);
     if (depth_keys) depth_keys[idx] = __float_as_uint(P.mc[2]);   // depth > 0: the bit pattern orders like the value
 }
 

@@ -55,8 +55,8 @@ _SIGNATURES = {
     "mi3dgs_adam_step": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_ll),
                               C.POINTER(_fl), _i, _fl, _fl, _fl, _f]),
     "mi3dgs_densify_decide": (_i, [_i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f]),
-    "mi3dgs_densify_scatter": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
-                                    C.POINTER(_f), _f, _f, _ll, _u32, _f]),
+    "mi3dgs_densify_scatter": (_i, [_i, _ll, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
+                                    C.POINTER(_f), _f, _f, _ll, _u32, _f, _f]),
     "mi3dgs_reset_opacity": (_i, [_i, _f, _fl, _f, _f, _f]),
     "mi3dgs_mcmc_relocation": (_i, [_i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_mcmc_inject_noise": (_i, [_i, _f, _f, _f, _f, _fl, _u32, _f]),
@@ -89,7 +89,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)     # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if handle.mi3dgs_abi_version() != 2:
+        if handle.mi3dgs_abi_version() != 3:
             raise Mi3dgsError("libmi3dgs.so ABI version mismatch")
         _lib = handle
     return _lib

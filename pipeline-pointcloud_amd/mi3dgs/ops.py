@@ -145,13 +145,15 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
               want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False,
-              fused: bool = True, depth_keys: Optional[torch.Tensor] = None):
+              fused: bool = True, depth_keys: Optional[torch.Tensor] = None, radii_in_records: bool = False):
     """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops
     the (tile, splat) pairs the ellipse sigma <= ln(255 o) cannot reach (identical renders and
     gradients, fewer intersections).  With max_isect=None the intersection count is read back (one host
     sync) and the outputs are sized exactly; otherwise outputs hold max_isect entries and
     the live count stays on the device (no sync).  depth_keys [C,N] int32 (fused path only): the sort
-    keys mi3dgs_project_fwd wrote beside its records; they are consumed."""
+    keys mi3dgs_project_fwd wrote beside its records; they are consumed.  radii_in_records: the records come from
+    mi3dgs_project_fwd (radii in slots 11, 12): one gather per splat in the emit pass."""
+    tight = int(bool(tight)) | (2 if radii_in_records else 0)
     Cn, N = radii.shape[0], radii.shape[1]
     dev = radii.device
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
@@ -169,7 +171,7 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
         tile_keys = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         offsets = torch.empty(Cn, th, tw, dtype=torch.int32, device=dev)
         isect_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
-        _lib.call("mi3dgs_bin_tiles", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+        _lib.call("mi3dgs_bin_tiles", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(tight),
                   _p(n_isect), cap, _p(flatten_ids), _p(tile_keys), _p(offsets), _p(isect_ids), _p(tpg), _p(depth_keys),
                   _p(ws), ws.numel(), st)
         out = dict(n_isect=n_isect, flatten_ids=flatten_ids, tile_keys=tile_keys, isect_offsets=offsets,
@@ -179,7 +181,7 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
         if want_tiles_per_gauss:
             out["tiles_per_gauss"] = tpg
         return out
-    _lib.call("mi3dgs_bin_count", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+    _lib.call("mi3dgs_bin_count", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(tight),
               _p(tpg), _p(n_isect), _p(ws), ws.numel(), cap, st)
     if not cap_known:
         cap = int(n_isect.item())
@@ -194,7 +196,7 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     tile_keys = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
     offsets = torch.empty(Cn, th, tw, dtype=torch.int32, device=dev)
     isect_ids = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
-    _lib.call("mi3dgs_bin_emit", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(bool(tight)),
+    _lib.call("mi3dgs_bin_emit", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(tight),
               _p(n_isect), cap, _p(flatten_ids),
               _p(tile_keys), _p(offsets), _p(isect_ids), _p(ws), ws.numel(), st)
     out = dict(n_isect=n_isect, flatten_ids=flatten_ids[:cap] if not cap_known else flatten_ids,

@@ -218,7 +218,7 @@ class Trainer:
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles,
-                                fused=self.cfg.fused_binning, depth_keys=keys)
+                                fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids
@@ -460,14 +460,13 @@ class Trainer:
             raise RuntimeError(f"refine would keep {new_n} Gaussians but capacity is {m.capacity}")
         src, dst = m.banks[m.cur], m.banks[1 - m.cur]
         seed = (self.cfg.seed * 1000003 + self.step_count * 7919 + 12345) & 0xFFFFFFFF
-        ops._lib.call("mi3dgs_densify_scatter", n,
+        ops._lib.call("mi3dgs_densify_scatter", n, new_n,
                       ops._ptr_array([src[g]["p"] for g in GROUPS]), ops._ptr_array([src[g]["m"] for g in GROUPS]),
                       ops._ptr_array([src[g]["v"] for g in GROUPS]), ops._ptr_array([dst[g]["p"] for g in GROUPS]),
                       ops._ptr_array([dst[g]["m"] for g in GROUPS]), ops._ptr_array([dst[g]["v"] for g in GROUPS]),
-                      ops._p(flags), ops._p(offs), m.capacity, seed, st)
-        fl = flags.to(torch.int32)
-        info = dict(n_before=n, n_after=new_n, n_dup=int(((fl & 1) != 0).logical_and((fl & 4) == 0).sum()),
-                    n_split=int(((fl & 2) != 0).logical_and((fl & 4) == 0).sum()), n_prune=int(((fl & 4) != 0).sum()))
+                      ops._p(flags), ops._p(offs), m.capacity, seed, ops._p(self.count_buf), st)   # count_buf: free after the scan
+        hist = torch.bincount(flags.to(torch.int64), minlength=8).tolist()            # one read-back for the log line
+        info = dict(n_before=n, n_after=new_n, n_dup=hist[1], n_split=hist[2], n_prune=hist[4] + hist[5] + hist[6] + hist[7])
         m.cur = 1 - m.cur
         m.n = new_n
         for v in self.stats.values():

@@ -131,7 +131,7 @@ def test_full_size_binning_bit_exact_and_raster_properties(dev, kind, cam):
     assert torch.equal(bf["tiles_per_gauss"], tpg_r)
     # (3) exact ellipse culling: a subset of the box lists, same order inside every tile, identical render
     bt = ops.bin_tiles(radii, splats, W, H, 16, max_isect=I + 4096, tight=True, fused=True, depth_keys=keys.clone(),
-                       want_tiles_per_gauss=True)
+                       want_tiles_per_gauss=True, radii_in_records=True)      # exactly the training step's call
     It = int(bt["n_isect"].item())
     assert 0 < It <= I and It == int(bt["tiles_per_gauss"].sum())
     tk, fi = bt["tile_keys"][:It].long(), bt["flatten_ids"][:It].long()
