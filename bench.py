@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--scene", default="garden", choices=["cube", "lego", "garden", "6m"])
     ap.add_argument("--gaussians", dest="n", type=int, default=None, help="override the Gaussian count")
     ap.add_argument("--views", type=int, default=8, help="target views kept resident")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "scene-shard"],
+                    help="replicas (default, BASELINE configs[3]): one independent scene per GPU, weak scaling.  scene-shard "
+                         "(configs[4]): ONE scene, Gaussians replicated, one view per rank per step, gradients reduce-scattered, "
+                         "Adam on a 1/G slice, parameters all-gathered; value = training views per second")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-profile", action="store_true")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
@@ -83,7 +87,7 @@ def build_workload(args, rank, dev):
     kw = {}
     if args.n:
         kw["n"] = args.n
-    seed = {"cube": 0, "lego": 1, "garden": 2, "6m": 3}[args.scene] + rank
+    seed = {"cube": 0, "lego": 1, "garden": 2, "6m": 3}[args.scene] + (0 if args.mode == "scene-shard" else rank)
     log(f"generating scene {args.scene} seed {seed}")
     sc = scenes.make_scene(args.scene, seed=seed, **kw)
     # targets come from a perturbed copy of the SAME Gaussians: the loss is non-trivial but the
@@ -117,7 +121,14 @@ def build_workload(args, rank, dev):
         # refine() after them and reports `refine_ms` and the amortised rate next to `value`
         refine_start_iter=10 ** 9,
         max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning)
-    tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
+    if args.mode == "scene-shard":
+        import dataclasses
+        from mi3dgs import parallel
+        ctx = parallel.DistContext(rank, int(os.environ.get("WORLD_SIZE", "1")), dev.index or 0)
+        tr = parallel.DataParallelTrainer(g.params, vm, ks, imgs, sc.width, sc.height,
+                                          dataclasses.replace(cfg, capacity=n, fuse_adam=ctx.world == 1), ctx=ctx)
+    else:
+        tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
     if not args.no_placement_tuning:
         tr.tune_placement(log=log)   # part of start-up, like the capacity sizing below; not inside the timed steps
     tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
@@ -260,14 +271,16 @@ def main():
             dist.barrier() if args.rehearse else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
+    shard = args.mode == "scene-shard"
+    view_of = (lambda i: (i * world + rank) % V) if shard else (lambda i: i % V)      # one view per rank per step
     log("warmup")
     for i in range(args.warmup):
-        tr.step(i % V)
+        tr.step(view_of(i))
     sync_all()
     log("timed region")
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tr.step(i % V)
+        tr.step(view_of(args.warmup + i))
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -303,6 +316,8 @@ def main():
         n_isect = int(tr.last["binning"]["n_isect"].item())
         n_vis = int((tr.radii[:, :n] > 0).all(-1).sum().item())
         stages, roof, render_roof = {}, None, None
+        if shard and world > 1:
+            args.no_stage_profile = True      # a step is collective in this mode: rank 0 can not run extra ones alone
         if not args.no_stage_profile:
             # per-kernel launch times: HIP events recorded by the library itself on the launch
             # stream around every kernel (include/mi3dgs.h: mi3dgs_profile_enable)
@@ -411,7 +426,7 @@ def main():
         # ---- one densify / prune pass at this size (every refine_every = 100 steps in training): decide +
         # scan + scatter of all parameter and moment rows into the spare bank + the host sync on the new count
         refine_runs = []
-        for rep in range(2):                 # the first call also pays the one-time set-up of a few tensor ops
+        for rep in range(0 if (shard and world > 1) else 2):      # the first call also pays the one-time set-up of a few tensor ops
             for i in range(3):               # fresh statistics for the pass
                 tr.step(i % V)
             torch.cuda.synchronize()
@@ -419,21 +434,28 @@ def main():
             rinfo = tr.refine(do_grow=True)
             torch.cuda.synchronize()
             refine_runs.append((1e3 * (time.perf_counter() - t2), rinfo))
-        refine_ms, rinfo = refine_runs[-1]
-        step_ms = 1e3 * dt / args.steps
-        refine = dict(refine_ms=refine_ms, first_call_ms=refine_runs[0][0], refine_every=100,
-                      **{k: rinfo[k] for k in ("n_before", "n_after", "n_dup", "n_split", "n_prune")},
-                      amortised_it_per_s=world * 1e3 / (step_ms + refine_ms / 100.0))
-        log(f"refine: {refine_ms:.2f} ms ({rinfo['n_before']} -> {rinfo['n_after']} Gaussians; first call {refine_runs[0][0]:.1f} ms)")
+        refine = None
+        if refine_runs:
+            refine_ms, rinfo = refine_runs[-1]
+            step_ms = 1e3 * dt / args.steps
+            refine = dict(refine_ms=refine_ms, first_call_ms=refine_runs[0][0], refine_every=100,
+                          **{k: rinfo[k] for k in ("n_before", "n_after", "n_dup", "n_split", "n_prune")},
+                          amortised_it_per_s=world * 1e3 / (step_ms + refine_ms / 100.0))
+            log(f"refine: {refine_ms:.2f} ms ({rinfo['n_before']} -> {rinfo['n_after']} Gaussians; first call {refine_runs[0][0]:.1f} ms)")
+        par = f"scene-per-gpu x{world}"
+        what = "one independent scene per GPU"
+        if shard:
+            par = f"one scene, view-per-rank x{world}, sharded optimiser (reduce-scatter / Adam on 1/{world} / all-gather)"
+            what = f"ONE scene on {world} GPUs, one view per rank per step; value counts training VIEWS per second"
         result = {
             "metric": "3DGS training iterations/s @1080p (render FPS reported alongside)",
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, "
-                                   "one independent scene per GPU", "gaussians": n, "visible": n_vis,
-                       "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
-                       "parallelism": f"scene-per-gpu x{world}"},
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, {what}",
+                       "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
+                       "parallelism": par, "mode": args.mode,
+                       "xgmi_bytes_per_rank_per_step": tr.xgmi_bytes_per_step() if shard else 0},
             "render_fps": fps, "roofline": roof, "render_roofline": render_roof, "refine": refine,
             "async_errors": async_bits, "cpu_baseline": cpu, "stages": stages,
         }

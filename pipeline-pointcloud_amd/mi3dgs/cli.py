@@ -179,10 +179,11 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     vm, ks = ds.viewmats[ds.train_idx].to(dev), ds.Ks[ds.train_idx].to(dev)
     if strategy == "mcmc":
         from .strategy_mcmc import MCMCConfig, MCMCTrainer
+        mc = MCMCConfig(cap_max=cap_max, refine_stop_iter=max(1, int(cfg.max_steps * 25 / 30)))
         if ctx is not None and ctx.active:
-            raise SystemExit("mi3dgs: the mcmc strategy is single-GPU only for now")
-        tr = MCMCTrainer(params, vm, ks, imgs, ds.width, ds.height, cfg,
-                         MCMCConfig(cap_max=cap_max, refine_stop_iter=max(1, int(cfg.max_steps * 25 / 30))))
+            tr = parallel.make_mcmc_data_parallel()(params, vm, ks, imgs, ds.width, ds.height, cfg, mc, ctx=ctx)
+        else:
+            tr = MCMCTrainer(params, vm, ks, imgs, ds.width, ds.height, cfg, mc)
     else:
         cls = parallel.DataParallelTrainer if (ctx is not None and ctx.active) else Trainer
         kw = {"ctx": ctx} if cls is parallel.DataParallelTrainer else {}
@@ -366,23 +367,24 @@ def _visible_gpus() -> int:
     return int(fake) if fake else torch.cuda.device_count()
 
 
-def main_simple_trainer(argv: Optional[List[str]] = None) -> int:
-    """Like gsplat's own launcher: one process per visible GPU (it ignores torchrun's env)."""
+def main_simple_trainer(argv: Optional[List[str]] = None, rank_fn=None) -> int:
+    """Like gsplat's own launcher: one process per visible GPU (it ignores torchrun's env).  rank_fn (tests): what
+    each spawned process runs instead of _simple_trainer_rank, same signature (rank, world, port, args)."""
+    rank_fn = rank_fn or _simple_trainer_rank
     a = parse_simple_trainer(sys.argv[1:] if argv is None else argv)
     world = _visible_gpus()
-    if a["strategy"] == "mcmc" and world > 1:
-        # The mcmc strategy runs on one GPU for now.  The reference still passes --steps_scaler 1/G
+    if os.environ.get("MI3DGS_SINGLE_GPU") and world > 1:
+        # Forced single-GPU run on a multi-GPU box.  The reference still passes --steps_scaler 1/G
         # (main.py:1322-1327: G images per step upstream, so 1/G of the steps); with one image per step
         # that would train 1/G of the job, so the division is undone here.
         a["steps_scaler"] = min(1.0, a["steps_scaler"] * world)
-        say(f"mcmc: training on one of the {world} visible GPUs; --steps_scaler reset to {a['steps_scaler']:g} "
-            "(one image per step)")
+        say(f"training on one of the {world} visible GPUs; --steps_scaler reset to {a['steps_scaler']:g} (one image per step)")
         world = 1
     if world <= 1:
-        _simple_trainer_rank(0, 1, 0, a)
+        rank_fn(0, 1, 0, a)
         return 0
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_simple_trainer_rank, args=(world, port, a), nprocs=world, join=True)
+    mp.spawn(rank_fn, args=(world, port, a), nprocs=world, join=True)
     return 0

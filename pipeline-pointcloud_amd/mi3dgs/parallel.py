@@ -27,7 +27,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .trainer import GROUPS, TrainConfig, Trainer
+from . import ops
+from .trainer import GROUPS, WIDTHS, TrainConfig, Trainer
 
 
 @dataclasses.dataclass
@@ -110,29 +111,123 @@ def batch_scaled_config(cfg: TrainConfig, batch: int) -> TrainConfig:
         reset_every=steps(cfg.reset_every), refine_every=steps(cfg.refine_every))
 
 
-class DataParallelTrainer(Trainer):
-    """Replicated-Gaussian data parallelism: identical parameters on every rank, one view per
-    rank per step, gradient mean and densify-statistics reductions over RCCL."""
+def _backend(group=None) -> str:
+    return dist.get_backend(group)
 
-    def __init__(self, *args, ctx: Optional[DistContext] = None, **kw):
-        super().__init__(*args, **kw)
+
+def reduce_scatter_sum_(flat: torch.Tensor, ctx: DistContext) -> torch.Tensor:
+    """Sum `flat` (numel divisible by world) over the ranks; returns this rank's 1/world slice (a view of `flat`,
+    in place).  RCCL: one reduce_scatter; gloo (CPU rehearsal, tests) has none: all_reduce and take the slice."""
+    L = flat.numel() // ctx.world
+    mine = flat[ctx.rank * L: (ctx.rank + 1) * L]
+    if _backend(ctx.group) == "nccl":
+        dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, group=ctx.group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+    return mine
+
+
+def all_gather_slices_(flat: torch.Tensor, ctx: DistContext) -> None:
+    """Every rank contributes its 1/world slice of `flat`; afterwards all ranks hold the whole buffer (in place)."""
+    L = flat.numel() // ctx.world
+    mine = flat[ctx.rank * L: (ctx.rank + 1) * L]
+    if _backend(ctx.group) == "nccl":
+        dist.all_gather_into_tensor(flat, mine, group=ctx.group)
+    else:
+        parts = [flat[r * L: (r + 1) * L] for r in range(ctx.world)]
+        dist.all_gather(parts, mine.clone(), group=ctx.group)
+
+
+class DataParallelMixin:
+    """Replicated-Gaussian data parallelism over a Trainer (default or MCMC strategy): identical parameters on
+    every rank, one view per rank per step.
+
+    shard_optimizer=True (SURVEY.md 8e(B)): gradients, parameters and moments live in flat buffers;
+        per step   reduce_scatter(gradients, sum)  ->  Adam on this rank's 1/G slice  ->  all_gather(parameters)
+        at refine  all_gather(exp_avg), all_gather(exp_avg_sq) (each rank only keeps its slice current), all-reduce
+                   of the densify statistics (sum, sum, max); then the identical surgery everywhere.
+      xGMI bytes per rank and step: 2 x (G-1)/G x 236 B x capacity  (6 M Gaussians, G = 8: 2.5 GB), against
+      2 x that for the dense all-reduce, and 1/G of the Adam traffic (1 652 B per Gaussian) instead of all of it.
+    shard_optimizer=False (round 1): one dense all-reduce per group, the full Adam step on every rank."""
+
+    def _dp_init(self, ctx: Optional[DistContext], shard_optimizer: bool):
         self.ctx = ctx or init_from_env()
+        self.shard_optimizer = bool(shard_optimizer) and self.ctx.active
+        self._moments_current = True            # False once a sharded Adam step has run since the last sync
+
+    def _model_layout(self) -> Dict:
+        ctx = getattr(self, "_pending_ctx", None)
+        world = ctx.world if ctx is not None else 1
+        if getattr(self, "_pending_shard", False) and world > 1:
+            return dict(flat=True, align=4 * world)            # slices stay 16-byte aligned
+        return {}
 
     def _live_grads(self) -> List[torch.Tensor]:
         m = self.model
         return [m.grads[g][: m.n] for g in GROUPS]
 
     def _can_fuse_adam(self) -> bool:
-        return not self.ctx.active          # the gradients have to exist to be all-reduced
+        return not self.ctx.active          # the gradients have to exist to be reduced
 
-    def _all_reduce_grads(self):
-        allreduce_mean_(self._live_grads(), self.ctx)
+    # -- the optimiser step --------------------------------------------------------------
+    def _slice_pieces(self):
+        """This rank's slice of the flat buffers as (group index, first element, count) pieces."""
+        m = self.model
+        tot = sum(WIDTHS) * m.capacity
+        L = tot // self.ctx.world
+        lo, hi = self.ctx.rank * L, (self.ctx.rank + 1) * L
+        out, off = [], 0
+        for gi, w in enumerate(WIDTHS):
+            g_lo, g_hi = off, off + w * m.n                    # live part of the group (rows beyond n are padding)
+            a, b = max(lo, g_lo), min(hi, g_hi)
+            if b > a:
+                out.append((gi, a, b - a))
+            off += w * m.capacity
+        return out
+
+    def _optimizer_step(self, n: int):
+        if not self.ctx.active:
+            return super()._optimizer_step(n)
+        c, m = self.cfg, self.model
+        if not self.shard_optimizer:
+            allreduce_mean_(self._live_grads(), self.ctx)
+            return super()._optimizer_step(n)
+        gflat = m.flat["g"]
+        reduce_scatter_sum_(gflat, self.ctx)
+        pieces = self._slice_pieces()
+        if pieces:
+            lrs = self.lrs()
+            P, M, V = m.flat["p"][m.cur], m.flat["m"][m.cur], m.flat["v"][m.cur]
+            inv = 1.0 / self.ctx.world
+            gs = [gflat[a: a + cnt].mul_(inv) for _, a, cnt in pieces]
+            ops.adam_step([P[a: a + cnt] for _, a, cnt in pieces], gs, [M[a: a + cnt] for _, a, cnt in pieces],
+                          [V[a: a + cnt] for _, a, cnt in pieces], [lrs[gi] for gi, _, _ in pieces], self.step_count + 1,
+                          beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps)
+        all_gather_slices_(m.flat["p"][m.cur], self.ctx)
+        self._moments_current = False
+
+    def _sync_optimizer_state(self):
+        """Bring exp_avg / exp_avg_sq up to date on every rank (each keeps only its slice current between refines)."""
+        if self.ctx.active and self.shard_optimizer and not self._moments_current:
+            m = self.model
+            all_gather_slices_(m.flat["m"][m.cur], self.ctx)
+            all_gather_slices_(m.flat["v"][m.cur], self.ctx)
+            self._moments_current = True
+
+    def xgmi_bytes_per_step(self) -> int:
+        """Bytes this rank sends (= receives) per training step for the gradient / parameter exchange."""
+        if not self.ctx.active:
+            return 0
+        G, m = self.ctx.world, self.model
+        if self.shard_optimizer:
+            return int(2 * (G - 1) / G * 4 * sum(WIDTHS) * m.capacity)
+        return int(2 * 2 * (G - 1) / G * 4 * sum(WIDTHS) * m.n)           # ring all-reduce = reduce-scatter + all-gather of everything
 
     def _async_error_bits(self) -> int:
         # every rank must take the same decision, or the ones that do not raise hang in the next collective
         bad = super()._async_error_bits()
         if self.ctx.active:
-            dev = self.device if dist.get_backend(self.ctx.group) == "nccl" else "cpu"
+            dev = self.device if _backend(self.ctx.group) == "nccl" else "cpu"
             t = torch.tensor([(bad >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)   # RCCL has no bitwise OR
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.ctx.group)
             bad = sum(int(v) << b for b, v in enumerate(t.tolist()))
@@ -140,6 +235,7 @@ class DataParallelTrainer(Trainer):
 
     def refine(self, do_grow: bool = True):
         n = self.model.n
+        self._sync_optimizer_state()
         allreduce_stats_({k: v[:n] for k, v in self.stats.items()}, self.ctx)
         return super().refine(do_grow)
 
@@ -159,3 +255,23 @@ class DataParallelTrainer(Trainer):
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.ctx.group)
             ok = ok and bool(torch.equal(lo, hi))
         return ok
+
+
+class DataParallelTrainer(DataParallelMixin, Trainer):
+    def __init__(self, *args, ctx: Optional[DistContext] = None, shard_optimizer: bool = True, **kw):
+        self._pending_ctx, self._pending_shard = ctx or init_from_env(), shard_optimizer
+        super().__init__(*args, **kw)
+        self._dp_init(self._pending_ctx, shard_optimizer)
+
+
+def make_mcmc_data_parallel():
+    """MCMC strategy over the same data-parallel machinery (class built lazily: strategy_mcmc imports trainer)."""
+    from .strategy_mcmc import MCMCTrainer
+
+    class MCMCDataParallelTrainer(DataParallelMixin, MCMCTrainer):
+        def __init__(self, *args, ctx: Optional[DistContext] = None, shard_optimizer: bool = True, **kw):
+            self._pending_ctx, self._pending_shard = ctx or init_from_env(), shard_optimizer
+            super().__init__(*args, **kw)
+            self._dp_init(self._pending_ctx, shard_optimizer)
+
+    return MCMCDataParallelTrainer

@@ -67,7 +67,7 @@ class MCMCTrainer(Trainer):
         self.mcmc_totals = dict(relocated=0, added=0)
 
     # gradients of the two regularisers, between the backward and Adam
-    def _all_reduce_grads(self):
+    def _grad_hooks(self):
         m, c = self.model, self.mcmc
         ops._lib.call("mi3dgs_mcmc_regularise", m.n, ops._p(m.p("opacities")), ops._p(m.p("scales")), float(c.opacity_reg),
                       float(c.scale_reg), ops._p(m.grad("opacities")), ops._p(m.grad("scales")), ops._stream(self.device))
@@ -105,9 +105,14 @@ class MCMCTrainer(Trainer):
             self._rows(g, "m")[sampled] = 0.0
             self._rows(g, "v")[sampled] = 0.0
 
+    def _sync_optimizer_state(self):
+        """Hook: the sharded data-parallel trainer brings every rank's Adam moments up to date here."""
+        return
+
     def relocate(self) -> int:
         m, c = self.model, self.mcmc
         n = m.n
+        self._sync_optimizer_state()
         op = torch.sigmoid(self._rows("opacities")[:n, 0])
         dead = op <= c.min_opacity
         n_dead = int(dead.sum())

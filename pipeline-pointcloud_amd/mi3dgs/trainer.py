@@ -84,23 +84,39 @@ class TrainConfig:
 class GaussianModel:
     """Parameter + Adam-moment store with spare capacity and two banks (densify ping-pong)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None):
+    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None, flat: bool = False, align: int = 1):
+        """flat: parameters, both moments and the gradients each live in ONE allocation, group after group
+        ([means | quats | scales | opacities | sh0 | shN], each [capacity, width]); the sharded optimiser
+        reduce-scatters / all-gathers those buffers whole (parallel.py).  align: capacity is rounded up to it."""
         dev = params["means"].device
         self.device = dev
         self.n = int(params["means"].shape[0])
         self.capacity = int(capacity or self.n)
         if self.capacity < self.n:
             raise ValueError("capacity smaller than the initial number of Gaussians")
+        self.capacity = (self.capacity + align - 1) // align * align
+        cap = self.capacity
+        self.flat: Optional[Dict] = None
         self.banks = []
-        for b in range(2):
-            bank = {}
-            for g, w in zip(GROUPS, WIDTHS):
-                bank[g] = {k: torch.zeros(self.capacity, w, dtype=torch.float32, device=dev) for k in ("p", "m", "v")}
-            self.banks.append(bank)
+        if flat:
+            tot = sum(WIDTHS) * cap
+            self.flat = {k: [torch.zeros(tot, dtype=torch.float32, device=dev) for _ in range(2)] for k in ("p", "m", "v")}
+            self.flat["g"] = torch.zeros(tot, dtype=torch.float32, device=dev)
+            offs = [sum(WIDTHS[:i]) * cap for i in range(len(WIDTHS))]
+            for b in range(2):
+                self.banks.append({g: {k: self.flat[k][b][o: o + w * cap].view(cap, w) for k in ("p", "m", "v")}
+                                   for g, w, o in zip(GROUPS, WIDTHS, offs)})
+            self.grads = {g: self.flat["g"][o: o + w * cap].view(cap, w) for g, w, o in zip(GROUPS, WIDTHS, offs)}
+        else:
+            for b in range(2):
+                bank = {}
+                for g, w in zip(GROUPS, WIDTHS):
+                    bank[g] = {k: torch.zeros(cap, w, dtype=torch.float32, device=dev) for k in ("p", "m", "v")}
+                self.banks.append(bank)
+            self.grads = {g: torch.zeros(cap, w, dtype=torch.float32, device=dev) for g, w in zip(GROUPS, WIDTHS)}
         self.cur = 0
         for g, w in zip(GROUPS, WIDTHS):
             self.banks[0][g]["p"][: self.n] = params[g].reshape(self.n, w).to(torch.float32)
-        self.grads = {g: torch.zeros(self.capacity, w, dtype=torch.float32, device=dev) for g, w in zip(GROUPS, WIDTHS)}
 
     def _view(self, t: torch.Tensor, g: str) -> torch.Tensor:
         return t[: self.n].view((self.n,) + _SHAPES[g])
@@ -123,7 +139,7 @@ class Trainer:
     def __init__(self, params: Dict[str, torch.Tensor], viewmats: torch.Tensor, Ks: torch.Tensor,
                  images: torch.Tensor, width: int, height: int, cfg: Optional[TrainConfig] = None):
         self.cfg = cfg or TrainConfig()
-        self.model = GaussianModel(params, self.cfg.capacity)
+        self.model = GaussianModel(params, self.cfg.capacity, **self._model_layout())
         dev = self.model.device
         self.device = dev
         self.viewmats, self.Ks = viewmats.to(dev).contiguous(), Ks.to(dev).contiguous()
@@ -155,6 +171,10 @@ class Trainer:
         self.refine_totals: Dict = {}
 
     # -- helpers -------------------------------------------------------------------
+    def _model_layout(self) -> Dict:
+        """Keyword arguments for GaussianModel (the sharded data-parallel trainer asks for flat buffers)."""
+        return {}
+
     def _n(self) -> int:
         return self.model.n
 
@@ -269,10 +289,8 @@ class Trainer:
                             sh_degree=sd, flags=self._flags(), out=grads, stats=stats, stat_use_abs=c.absgrad)
             if sreg:
                 ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
-            self._all_reduce_grads()
-            ops.adam_step([bank[g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
-                          [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, beta1=c.adam_beta1,
-                          beta2=c.adam_beta2, eps=c.adam_eps, numel=[n * w for w in WIDTHS])
+            self._grad_hooks()
+            self._optimizer_step(n)
         if c.densify:
             self._strategy_post_step()
         self.last = dict(binning=binning, sums=sums)
@@ -408,9 +426,18 @@ class Trainer:
                 f"bank {b} {report[f'bank{b}_first_us']:.0f} -> {report[f'bank{b}_tuned_us']:.0f} us" for b in range(len(m.banks))))
         return report
 
-    def _all_reduce_grads(self):
-        """Hook for the replicated-Gaussian data-parallel mode (parallel.py); no-op on one GPU."""
+    def _grad_hooks(self):
+        """Extra gradient terms between the backward and the optimiser (the MCMC regularisers)."""
         return
+
+    def _optimizer_step(self, n: int):
+        """Adam over all six groups from the materialised gradients.  The data-parallel trainers override this:
+        gradient mean over the ranks first (parallel.py), or reduce-scatter -> Adam on a slice -> all-gather."""
+        c, m = self.cfg, self.model
+        bank = m.banks[m.cur]
+        ops.adam_step([bank[g]["p"] for g in GROUPS], [m.grads[g] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
+                      [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, beta1=c.adam_beta1,
+                      beta2=c.adam_beta2, eps=c.adam_eps, numel=[n * w for w in WIDTHS])
 
     def _can_fuse_adam(self) -> bool:
         return True

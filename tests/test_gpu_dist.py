@@ -38,12 +38,31 @@ def _worker(rank, world, port, q):
                                   grow_grad2d=1e-5, sh_degree_interval=2, seed=5)
         g = torch.Generator().manual_seed(3)
         imgs = torch.rand(4, 64, 96, 3, generator=g).to(dev)
-        tr = parallel.DataParallelTrainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, cfg, ctx=ctx)
+        tr = parallel.DataParallelTrainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, cfg, ctx=ctx)      # sharded optimiser
+        assert tr.shard_optimizer and tr.model.flat is not None
+        dense = parallel.DataParallelTrainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, cfg, ctx=ctx, shard_optimizer=False)
         n0 = tr.model.n
-        sync = []
+        sync, same = [], []
         for s in range(10):
             tr.step_global()
-            sync.append(tr.replicas_in_sync())
+            dense.step_global()
+            sync.append(tr.replicas_in_sync() and dense.replicas_in_sync())
+            # reduce-scatter + Adam on a slice + all-gather == dense mean + full Adam, refine included.  (Two separate
+            # backward passes: their float atomics sum in different orders, and Adam with eps 1e-15 amplifies the last
+            # bits; the exact equivalence on identical gradients is tests/test_dist_cpu.py's.)
+            from helpers import rel_err
+            same.append(tr.model.n == dense.model.n and all(rel_err(tr.model.p(k), dense.model.p(k)) < 2e-3 for k in trainer.GROUPS))
+        tr.check_async_errors()
+        # the MCMC strategy over the same machinery: relocation / growth decisions must be identical on every rank
+        from mi3dgs.strategy_mcmc import MCMCConfig
+        mc = parallel.make_mcmc_data_parallel()(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64,
+                                                trainer.TrainConfig(max_steps=100, seed=5, sh_degree_interval=2),
+                                                MCMCConfig(cap_max=2000, refine_start_iter=1, refine_every=3, refine_stop_iter=50), ctx=ctx)
+        nm0 = mc.model.n
+        for s in range(9):
+            mc.step_global()
+            sync.append(mc.replicas_in_sync())
+        mcmc_grew = mc.model.n > nm0
         # control: without the reductions the replicas must drift (the test would be vacuous otherwise)
         tr2 = trainer.Trainer(sc.params, sc.viewmats, sc.Ks, imgs, 96, 64, trainer.TrainConfig(densify=False))
         tr2.step(rank)
@@ -51,7 +70,8 @@ def _worker(rank, world, port, q):
         lo, hi = p.clone(), p.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        q.put((rank, dict(sync=all(sync), n0=n0, n=tr.model.n, drift=not torch.equal(lo, hi))))
+        q.put((rank, dict(sync=all(sync), same=all(same), n0=n0, n=tr.model.n, drift=not torch.equal(lo, hi), mcmc_grew=mcmc_grew,
+                          mcmc_n=mc.model.n)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:
@@ -74,5 +94,8 @@ def test_replicas_stay_identical_through_adam_and_refine(dev):
     for r in range(world):
         assert "error" not in res[r], res[r].get("error")
         assert res[r]["sync"], "replicas diverged"
+        assert res[r]["same"], "sharded optimiser and dense all-reduce disagree"
+        assert res[r]["mcmc_grew"]
         assert res[r]["drift"], "control run did not drift: the test is vacuous"
     assert res[0]["n"] == res[1]["n"] and res[0]["n"] != res[0]["n0"], res   # a refine pass really changed N
+    assert res[0]["mcmc_n"] == res[1]["mcmc_n"]
