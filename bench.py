@@ -56,8 +56,10 @@ def parse():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
-    ap.add_argument("--no-placement-tuning", action="store_true",
-                    help="A/B: skip Trainer.tune_placement (HBM placement of the parameter / moment arrays)")
+    ap.add_argument("--placement-tuning", action="store_true",
+                    help="A/B: run Trainer.tune_placement first (start-up search over the HBM placement of the parameter / "
+                         "moment arrays; off by default since round 2: the flat model layout needs no lottery)")
+    ap.add_argument("--no-placement-tuning", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling, now the default
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
@@ -129,7 +131,7 @@ def build_workload(args, rank, dev):
                                           dataclasses.replace(cfg, capacity=n, fuse_adam=ctx.world == 1), ctx=ctx)
     else:
         tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
-    if not args.no_placement_tuning:
+    if args.placement_tuning:
         tr.tune_placement(log=log)   # part of start-up, like the capacity sizing below; not inside the timed steps
     tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
     if not args.sync_isect:

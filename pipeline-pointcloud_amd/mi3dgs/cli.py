@@ -188,7 +188,8 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
         cls = parallel.DataParallelTrainer if (ctx is not None and ctx.active) else Trainer
         kw = {"ctx": ctx} if cls is parallel.DataParallelTrainer else {}
         tr = cls(params, vm, ks, imgs, ds.width, ds.height, cfg, **kw)
-    tr.tune_placement(log=say if (ctx is None or ctx.rank == 0) else None)
+    if os.environ.get("MI3DGS_TUNE_PLACEMENT"):
+        tr.tune_placement(log=say if (ctx is None or ctx.rank == 0) else None)
     say(f"loaded in {time.time() - t0:.1f}s; training {cfg.max_steps} steps from {tr.model.n} Gaussians "
         f"(capacity {tr.model.capacity})")
     V = len(ds.train_idx)

@@ -173,7 +173,12 @@ class Trainer:
     # -- helpers -------------------------------------------------------------------
     def _model_layout(self) -> Dict:
         """Keyword arguments for GaussianModel (the sharded data-parallel trainer asks for flat buffers)."""
-        return {}
+        # One allocation per kind (parameters, exp_avg, exp_avg_sq, gradients) instead of eighteen: the fused backward +
+        # Adam kernel streams all of them at once and its speed depends on where their pages landed (DESIGN.md,
+        # "placement").  With separate allocations it ran 588-589 us without the start-up search, flat 548-575 us on the
+        # same box (gpurun_out/r2k, tools/placement_ab.sh); the search (Trainer.tune_placement) is now opt-in.
+        import os
+        return {} if os.environ.get("MI3DGS_SEPARATE_ARRAYS") else dict(flat=True)
 
     def _n(self) -> int:
         return self.model.n
@@ -312,6 +317,10 @@ class Trainer:
         Costs a few hundred milliseconds and, transiently, a few GB."""
         c, m = self.cfg, self.model
         if not (c.fuse_adam and self._can_fuse_adam()) or self.step_count != 0:
+            return {}
+        if m.flat is not None:                  # the search re-allocates single arrays; the flat layout has none
+            if log is not None:
+                log("placement: flat model layout, nothing to tune (MI3DGS_SEPARATE_ARRAYS=1 restores the round-1 layout)")
             return {}
         if m.n < min_gaussians:                  # the kernel is launch-bound down here; nothing to gain
             return {}
