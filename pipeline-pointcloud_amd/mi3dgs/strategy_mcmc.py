@@ -91,8 +91,12 @@ class MCMCTrainer(Trainer):
     def _rows(self, g: str, k: str = "p") -> torch.Tensor:
         return self.model.banks[self.model.cur][g][k]
 
-    def _apply_relocation(self, sampled: torch.Tensor):
-        """New opacity / scale for the sampled sources (ratio = times sampled + 1); zero their Adam state."""
+    def _apply_relocation(self, sampled: torch.Tensor, zero_source_state: bool = True):
+        """New opacity / scale for the sampled sources (ratio = times sampled + 1).  gsplat's `relocate` also zeroes
+        the sources' Adam state, its `sample_add` does NOT (only the appended copies start from zero moments): a
+        source whose moments are zeroed takes a ~3 x lr step in every coordinate at the next Adam update (the bias
+        correction is the global step's), and growth samples 5 % of the most opaque Gaussians every 100 steps.
+        [UPSTREAM-UNVERIFIED]"""
         m, c = self.model, self.mcmc
         op = torch.sigmoid(self._rows("opacities")[sampled, 0])
         sc = torch.exp(self._rows("scales")[sampled])
@@ -101,9 +105,10 @@ class MCMCTrainer(Trainer):
         no = no.clamp(min=c.min_opacity, max=1.0 - 1e-7)
         self._rows("opacities")[sampled, 0] = torch.log(no / (1.0 - no))
         self._rows("scales")[sampled] = torch.log(ns)
-        for g in GROUPS:
-            self._rows(g, "m")[sampled] = 0.0
-            self._rows(g, "v")[sampled] = 0.0
+        if zero_source_state:
+            for g in GROUPS:
+                self._rows(g, "m")[sampled] = 0.0
+                self._rows(g, "v")[sampled] = 0.0
 
     def _sync_optimizer_state(self):
         """Hook: the sharded data-parallel trainer brings every rank's Adam moments up to date here."""
@@ -135,8 +140,9 @@ class MCMCTrainer(Trainer):
         if n_new == 0:
             return 0
         op = torch.sigmoid(self._rows("opacities")[:n, 0])
+        self._sync_optimizer_state()
         sampled = torch.multinomial(op, n_new, replacement=True, generator=self.tgen)
-        self._apply_relocation(sampled)
+        self._apply_relocation(sampled, zero_source_state=False)
         for g in GROUPS:
             self._rows(g)[n:n + n_new] = self._rows(g)[sampled]
             self._rows(g, "m")[n:n + n_new] = 0.0

@@ -569,16 +569,45 @@ def test_mcmc_trainer_relocates_and_grows(dev):
     assert float(moved.min()) > 0                                   # teleported onto live Gaussians
     same = (tr.model.p("means")[:200, None, :] == before_means[None, 200:, :]).all(-1).any(1)
     assert bool(same.all())                                          # bit-exact copies of live positions
+    # growth (gsplat sample_add): the appended copies start from zero moments, the SOURCES keep theirs (relocate
+    # zeroes them; doing the same here kicked 5 % of the most opaque Gaussians by ~3 x lr every 100 steps and cost
+    # 3.5 dB on the long synthetic run, profiles/r02_train_synthetic.txt)
+    for k in trainer.GROUPS:
+        tr.model.state(k, "m").fill_(0.25)
+        tr.model.state(k, "v").fill_(0.5)
     n_new = tr.add_new()
     assert n_new == 50 and tr.model.n == 1050                       # +5 %
-    assert float(tr.model.state("means", "m")[1000:].abs().max()) == 0
+    assert float(tr.model.state("means", "m")[1000:].abs().max()) == 0 and float(tr.model.state("shN", "v")[1000:].abs().max()) == 0
+    assert float(tr.model.state("means", "m")[:1000].min()) == 0.25 and float(tr.model.state("opacities", "v")[:1000].min()) == 0.5
+    src = (tr.model.p("means")[1000:, None, :] == tr.model.p("means")[None, :1000, :]).all(-1)
+    assert bool(src.any(1).all())                                   # every new Gaussian sits on one of the old ones
+    tr.model.state("means", "m")[:200] = 0.25
+    n_rel2 = tr.relocate()                                          # nothing is dead now
+    assert n_rel2 == 0
     for s in range(12):
         tr.step(s % 4)
     assert tr.model.n == 1200                                       # capped at cap_max
     assert all(torch.isfinite(tr.model.p(k)).all() for k in trainer.GROUPS)
 
 
-def test_placement_tuning_is_a_no_op_on_the_model(dev):
+def test_mcmc_regulariser_gradients_match_autograd(dev):
+    """loss += opacity_reg * mean(sigmoid(o)) + scale_reg * mean(exp(s))  (gsplat simple_trainer, mcmc preset):
+    the kernel ADDS exactly that gradient to what the backward left, with the 1/N and 1/(3N) of the two means."""
+    ops = _ops()
+    n = 777
+    g = torch.Generator().manual_seed(5)
+    o = (torch.randn(n, generator=g) * 2).double().requires_grad_(True)
+    sl = (torch.randn(n, 3, generator=g) - 3).double().requires_grad_(True)
+    (0.01 * torch.sigmoid(o).mean() + 0.02 * torch.exp(sl).mean()).backward()
+    vo = torch.full((n,), 0.5, device=dev)
+    vs = torch.full((n, 3), -0.25, device=dev)
+    ops._lib.call("mi3dgs_mcmc_regularise", n, ops._p(o.detach().float().to(dev)), ops._p(sl.detach().float().to(dev).contiguous()),
+                  0.01, 0.02, ops._p(vo), ops._p(vs), ops._stream(dev))
+    assert rel_err(vo.cpu() - 0.5, o.grad) < 1e-5 and rel_err(vs.cpu() + 0.25, sl.grad) < 1e-5
+
+
+def test_placement_tuning_is_a_no_op_on_the_model(dev, monkeypatch):
+    monkeypatch.setenv("MI3DGS_SEPARATE_ARRAYS", "1")      # the search works on separately allocated arrays (round-1 layout)
     """tune_placement() re-allocates arrays and times the fused kernel as an exact no-op: parameters, moments and
     densify statistics are what they were, and training afterwards is what it would have been."""
     from mi3dgs import trainer
