@@ -1,0 +1,91 @@
+"""A real trained splat through the whole drop-in path.  NOT the reference's container and NOT a
+dataset of photographs: the only real asset the reference ships, source/Gradio/favorites/wolf.spz (committed as the
+data fixture tests/golden/wolf.spz, decoded by the reference's own codec oracle/_ref/splat_converter), is rendered
+by this engine from a ring of cameras to 8-bit PNGs, a COLMAP model with a SUB-SAMPLED, jittered point cloud is
+written next to them, and the `ns-train` / `ns-export` shims train from that to held-out PSNR: real anisotropic
+Gaussians and real SH as the target, u8 images, densification growing N, export in the trainer's frame.
+
+  python tools/train_wolf.py --steps 7000 [--views 60 --width 960 --height 720 --points 9000]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pipeline-pointcloud_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=60)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--points", type=int, default=9000)
+    ap.add_argument("--steps", type=int, default=7000)
+    ap.add_argument("--model", default="splatfacto")
+    a = ap.parse_args()
+    from PIL import Image
+    from helpers import load_wolf
+    from mi3dgs import cli, io_colmap, io_ply, scenes, trainer
+    dev = torch.device("cuda:0")
+    root = tempfile.mkdtemp(prefix="mi3dgs_wolf_")
+    os.makedirs(os.path.join(root, "images"))
+    P = load_wolf()
+    n = P["means"].shape[0]
+    centre = P["means"].median(0).values
+    ext = float((P["means"] - centre).abs().quantile(0.99))
+    g = {k: v.to(dev) for k, v in P.items()}
+    fx = 1.25 * a.width
+    vms, ks = [], []
+    for i in range(a.views):
+        az = 2.0 * math.pi * i / a.views
+        el = 0.25 + 0.35 * math.sin(3.0 * az)                          # wobbling ring: views from several heights
+        r = 3.2 * ext
+        eye = centre + torch.tensor([r * math.cos(az) * math.cos(el), -r * math.sin(el), r * math.sin(az) * math.cos(el)])
+        vms.append(scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0)))
+        ks.append(scenes._intrinsics(fx, a.width, a.height))
+    vms, ks = torch.stack(vms), torch.stack(ks)
+    tr = trainer.Trainer(g, vms.to(dev), ks.to(dev), torch.zeros(1, 1, 1, 3, device=dev), a.width, a.height,
+                         trainer.TrainConfig(densify=False))
+    bg = torch.full((1, 3), 0.15, device=dev)
+    cams = [io_colmap.Camera(1, "PINHOLE", a.width, a.height, np.array([fx, fx, a.width / 2, a.height / 2]))]
+    ims, cover = [], []
+    for i in range(a.views):
+        img, al = tr.render(vms[i].to(dev), ks[i].to(dev), background=bg)
+        cover.append(float((al > 0.5).float().mean()))
+        Image.fromarray((img[0].clamp(0, 1) * 255).round().byte().cpu().numpy()).save(os.path.join(root, "images", f"f_{i:04d}.png"))
+        V = vms[i].double().numpy()
+        ims.append(io_colmap.Image(i + 1, io_colmap.rotmat_to_qvec(V[:3, :3]), V[:3, 3].copy(), 1, f"f_{i:04d}.png"))
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(1))[: a.points]
+    xyz = (P["means"][sel] + 0.002 * ext * torch.randn(a.points, 3)).double().numpy()
+    rgb = ((0.5 + 0.2820948 * P["sh0"][sel, 0]).clamp(0, 1) * 255).byte().numpy()
+    io_colmap.write_model(os.path.join(root, "colmap", "sparse", "0"), cams, ims, xyz, rgb)
+    del tr
+    torch.cuda.empty_cache()
+    print(f"[wolf] target: {n} Gaussians of the reference's wolf.spz (real SH, extent {ext:.3f}); {a.views} views "
+          f"{a.width}x{a.height} u8 PNG, object covers {100 * sum(cover) / len(cover):.0f} % of a frame; "
+          f"{a.points} of {n} points (jittered) as the SfM cloud", flush=True)
+    os.chdir(root)
+    t0 = time.time()
+    cli.main_ns_train([a.model, "--timestamp", "train-stage-1", "--viewer.quit-on-train-completion=True",
+                       "--logging.local-writer.enable", "False", "--logging.profiler", "none",
+                       "--pipeline.model.use_scale_regularization=True", "--max-num-iterations", str(a.steps),
+                       "colmap", "--data", root, "--downscale-factor", "1"])
+    base = os.path.join("outputs", "unnamed", "splatfacto", "train-stage-1")
+    cli.main_ns_export(["gaussian-splat", "--load-config", os.path.join(base, "config.yml"), "--output-dir", os.path.join(root, "exports")])
+    st = json.loads("".join(l for l in open(os.path.join(base, "config.yml")) if not l.startswith("#")))["stats"]
+    out = io_ply.read_ply(os.path.join(root, "exports", "splat.ply"))
+    print(f"[wolf] result: {json.dumps(st)}; exported {out['means'].shape[0]} Gaussians from {a.points} seed points "
+          f"in {time.time() - t0:.1f}s wall (training frame: z-up, unit cube)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
