@@ -156,6 +156,19 @@ __device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane
     }
 }
 
+// The chain reads one wave-uniform float4 per visit (the splat's colour).  hipcc treats the LDS address as a
+// scalar and re-materialises it into a VGPR for every read (a v_mov per visit in VALU-issue-bound loops); an
+// opaque per-sub-batch VGPR base keeps the row index in the instruction's immediate offset instead.
+struct Rgb { float x, y, z; };
+struct F4pod { float x, y, z, w; };
+typedef __attribute__((address_space(3))) const F4pod* lds_f4_ptr;
+__device__ __forceinline__ lds_f4_ptr opaque_lds_base(const float4* p) {
+    lds_f4_ptr q = (lds_f4_ptr)reinterpret_cast<const F4pod*>(p);
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ Rgb lds_rgb(lds_f4_ptr p, int i) { return Rgb{p[i].x, p[i].y, p[i].z}; }
+
 // alpha of a pair from its log2: min(0.999, o vis).  (sigma is not clamped at 0: a PSD form evaluated through the
 // six-term chain can come out up to ~3e-4 positive in log2 units at the splat centre, i.e. alpha up to 1.0002 o.)
 // The membership test alpha >= 1/255 is taken in the log domain, on the MFMA result itself: a visit that no lane
@@ -199,12 +212,13 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
             if (live == 0ull) break;
             float s[SUB];
             eval_sub_batch(L, sb, lane, basis, s);
-            float4 col_next = L.uni[sb * SUB];
+            const lds_f4_ptr uni = opaque_lds_base(&L.uni[sb * SUB]);
+            Rgb col_next = lds_rgb(uni, 0);
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
                 if ((i & 7) == 0 && i > 0 && live == 0ull) break;
-                const float4 col = col_next;
-                col_next = L.uni[sb * SUB + i + 1];             // one visit ahead: its latency hides behind this visit
+                const Rgb col = col_next;
+                col_next = lds_rgb(uni, i + 1);                 // one visit ahead: its latency hides behind this visit
                 const unsigned long long hit = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & live;
                 if (hit == 0ull) continue;
                 const float alpha = alpha_of(s[i]);
@@ -245,7 +259,6 @@ struct StagedBwd {
     float2 geo2[BLOCK];       // C, 1 / o
     int id[BLOCK];
     float acc[BLOCK][AC_STRIDE];
-    int touched[BLOCK];
     int wave_max[4];
 };
 
@@ -257,12 +270,15 @@ template <bool ABSGRAD, bool FAST>
 __device__ __forceinline__ void bwd_sub_batch(StagedBwd& L, const float (&s)[SUB], int sb, int be, int lane, int bin_final,
                                               unsigned long long has, const PixelBasis& px, const float (&vrgb)[3], float tail,
                                               float& T, float& bufdot) {
-    float4 col_next = L.f.uni[sb * SUB];
+    const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
+    Rgb col_next = lds_rgb(uni, 0);
+    const bool adds = (lane & 7) == 0 || lane == 63;
+    float* acc_lane = &L.acc[sb * SUB][lane == 63 ? AC_B : (lane >> 3)];
 #pragma unroll
     for (int i = 0; i < SUB; i++) {
         const int k = sb * SUB + i;
-        const float4 col = col_next;
-        col_next = L.f.uni[k + 1];
+        const Rgb col = col_next;
+        col_next = lds_rgb(uni, i + 1);
         // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
         unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
         if (!FAST) valid &= mask_ge_i(bin_final, be - k);
@@ -293,14 +309,10 @@ __device__ __forceinline__ void bwd_sub_batch(StagedBwd& L, const float (&s)[SUB
         // reduce-scatter: lane l ends with the total of value number (l >> 3) in qu, lane 63 with g_b's
         wave_reduce_scatter8_plus1(qu, qv, quu, quv, qvv, q, g_r, g_g, g_b);
         if (ABSGRAD) { g_ax = wave_sum_to_lane63(g_ax); g_ay = wave_sum_to_lane63(g_ay); }
-        {
-            const bool last = lane == 63;
-            if ((lane & 7) == 0 || last) atomicAdd(&L.acc[k][last ? AC_B : (lane >> 3)], last ? g_b : qu);
-            if (last) {
-                if (ABSGRAD) { atomicAdd(&L.acc[k][AC_ABSX], g_ax); atomicAdd(&L.acc[k][AC_ABSY], g_ay); }
-                L.touched[k] = 1;
-            }
-        }
+        // one 9-lane LDS atomic per (quadrant, splat); `acc_lane` already points at this lane's component of the
+        // sub-batch's first row, so the row is an immediate offset
+        if (adds) atomicAdd(acc_lane + i * AC_STRIDE, lane == 63 ? g_b : qu);
+        if (ABSGRAD && lane == 63) { atomicAdd(&L.acc[k][AC_ABSX], g_ax); atomicAdd(&L.acc[k][AC_ABSY], g_ay); }
     }
 }
 
@@ -371,7 +383,6 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < AC_STRIDE; k++) L.acc[threadIdx.x][k] = 0.f;
-        L.touched[threadIdx.x] = 0;
         {
             const bool in_list = idx >= start;
             const int id = in_list ? flatten_ids[idx] : 0;
@@ -403,7 +414,12 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
         for (int sl = wv * 64; sl < wv * 64 + 64; sl += 4) {
             const int slot = sl + (lane >> 4);
             const int comp = lane & 15;
-            if (slot < bsz && L.touched[slot] && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
+            // a slot no pixel touched (or whose sums all cancelled to exactly zero) has nothing to add: its 16 lanes
+            // find that out together from the raw sums, no per-visit "touched" flag
+            const bool any_raw = slot < bsz && comp < AC_STRIDE && L.acc[slot][comp < AC_STRIDE ? comp : 0] != 0.f;
+            const unsigned long long nz = wave_ballot(any_raw);
+            const bool touched = ((nz >> (lane & 48)) & 0xFFFFull) != 0ull;
+            if (slot < bsz && touched && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
                 const float* ac = L.acc[slot];
                 const float M = ac[AC_Q], Mu = ac[AC_QU], Mv = ac[AC_QV];
                 const float4 ge = L.geo[slot];

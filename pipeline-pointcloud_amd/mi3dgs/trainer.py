@@ -94,6 +94,8 @@ class GaussianModel:
         self.capacity = int(capacity or self.n)
         if self.capacity < self.n:
             raise ValueError("capacity smaller than the initial number of Gaussians")
+        if flat:
+            align = max(align, 4) // 4 * 4 if align % 4 == 0 else align * 4      # every group then starts 16-byte aligned
         self.capacity = (self.capacity + align - 1) // align * align
         cap = self.capacity
         self.flat: Optional[Dict] = None
