@@ -258,6 +258,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     hist[threadIdx.x * B + blockIdx.x] = h[threadIdx.x];
 }
 
+// BITS = width of this pass's digit: the match-any ranking below costs one ballot + a 64-bit per-lane select per
+// digit bit and key, and the tile sort's passes are 7 and 6 bits wide, not 8 (the kernel is VALU bound on it)
+template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t d = (key[r] >> shift) & mask;
         unsigned long long peers = wave_ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             bool bit = (d >> b) & 1u;
             unsigned long long m = wave_ballot(bit);
             peers &= bit ? m : ~m;
@@ -591,8 +594,16 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
         int rc = scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, s0);
         if (rc) return rc;
-        MI_LAUNCH(ctag, rs_scatter_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
-                           hist, B);
+#define RS_SCATTER(NB) MI_LAUNCH(ctag, rs_scatter_kernel<NB>, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, \
+                                 n_ptr, cap, shift, mask, hist, B)
+        switch (bits) {
+            case 1: case 2: case 3: case 4: RS_SCATTER(4); break;
+            case 5: RS_SCATTER(5); break;
+            case 6: RS_SCATTER(6); break;
+            case 7: RS_SCATTER(7); break;
+            default: RS_SCATTER(8); break;
+        }
+#undef RS_SCATTER
         MI_LAUNCH_CHECK();
         uint32_t* t;
         t = ki; ki = ko; ko = t;

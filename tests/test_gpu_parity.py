@@ -599,11 +599,14 @@ def test_mcmc_regulariser_gradients_match_autograd(dev):
     o = (torch.randn(n, generator=g) * 2).double().requires_grad_(True)
     sl = (torch.randn(n, 3, generator=g) - 3).double().requires_grad_(True)
     (0.01 * torch.sigmoid(o).mean() + 0.02 * torch.exp(sl).mean()).backward()
-    vo = torch.full((n,), 0.5, device=dev)
-    vs = torch.full((n, 3), -0.25, device=dev)
-    ops._lib.call("mi3dgs_mcmc_regularise", n, ops._p(o.detach().float().to(dev)), ops._p(sl.detach().float().to(dev).contiguous()),
-                  0.01, 0.02, ops._p(vo), ops._p(vs), ops._stream(dev))
-    assert rel_err(vo.cpu() - 0.5, o.grad) < 1e-5 and rel_err(vs.cpu() + 0.25, sl.grad) < 1e-5
+    vo = torch.zeros(n, device=dev)
+    vs = torch.zeros(n, 3, device=dev)
+    args = (n, ops._p(o.detach().float().to(dev)), ops._p(sl.detach().float().to(dev).contiguous()), 0.01, 0.02, ops._p(vo), ops._p(vs),
+            ops._stream(dev))
+    ops._lib.call("mi3dgs_mcmc_regularise", *args)
+    assert rel_err(vo.cpu(), o.grad) < 1e-5 and rel_err(vs.cpu(), sl.grad) < 1e-5
+    ops._lib.call("mi3dgs_mcmc_regularise", *args)                      # accumulates (the backward's gradient is in there first)
+    assert rel_err(vo.cpu(), 2 * o.grad) < 1e-5 and rel_err(vs.cpu(), 2 * sl.grad) < 1e-5
 
 
 def test_placement_tuning_is_a_no_op_on_the_model(dev, monkeypatch):

@@ -2,7 +2,7 @@
 import csv, re, sys
 from collections import defaultdict
 def short(n):
-    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = n.replace("(anonymous namespace)::", "").replace("mfma_raster::", "").replace("void ", "")
     return re.sub(r"_kernel$", "", re.sub(r"[<(].*", "", n))
 files = [a for a in sys.argv[1:] if not a.startswith("--")]
 want = None

@@ -13,7 +13,7 @@ from collections import defaultdict
 
 
 def short(name):
-    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = name.replace("(anonymous namespace)::", "").replace("mfma_raster::", "").replace("void ", "")
     # bench.py's profiler tags: the fused single-camera backward is "project_bwd_adam"
     n = n.replace("project_bwd1_kernel<true, true>", "project_bwd_adam_probe").replace("project_bwd1_kernel<true, false>", "project_bwd_adam")
     n = n.replace("project_bwd1_kernel<false, false>", "project_bwd")
