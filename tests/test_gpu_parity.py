@@ -601,8 +601,8 @@ def test_mcmc_regulariser_gradients_match_autograd(dev):
     (0.01 * torch.sigmoid(o).mean() + 0.02 * torch.exp(sl).mean()).backward()
     vo = torch.zeros(n, device=dev)
     vs = torch.zeros(n, 3, device=dev)
-    args = (n, ops._p(o.detach().float().to(dev)), ops._p(sl.detach().float().to(dev).contiguous()), 0.01, 0.02, ops._p(vo), ops._p(vs),
-            ops._stream(dev))
+    o_d, sl_d = o.detach().float().to(dev), sl.detach().float().to(dev).contiguous()      # (named: a raw pointer keeps nothing alive)
+    args = (n, ops._p(o_d), ops._p(sl_d), 0.01, 0.02, ops._p(vo), ops._p(vs), ops._stream(dev))
     ops._lib.call("mi3dgs_mcmc_regularise", *args)
     assert rel_err(vo.cpu(), o.grad) < 1e-5 and rel_err(vs.cpu(), sl.grad) < 1e-5
     ops._lib.call("mi3dgs_mcmc_regularise", *args)                      # accumulates (the backward's gradient is in there first)
