@@ -158,6 +158,9 @@ int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits
  * (one histogram kernel for all passes, one chained-look-back kernel per pass), 2 = onesweep
  * up to 4 M keys, classic above (the default; see binning.hip for the measurements). */
 int mi3dgs_debug_set_sort_mode(int mode);
+/* A/B switch for the fused exact emit of mi3dgs_bin_tiles: 1 (default) = wave-granular (one wave = 64 depth-sorted
+ * splats, no barriers), 0 = block-cooperative (round 1).  Same output bit for bit. */
+int mi3dgs_debug_set_emit_mode(int mode);
 /* The chained kernels (onesweep radix pass, device-wide scan, fused tile emit) wait on one another
  * with BOUNDED spins; a wait that runs out sets a bit in one device word instead of hanging the
  * GPU, and the results of that call are then wrong.  This reads (and optionally clears) the word;

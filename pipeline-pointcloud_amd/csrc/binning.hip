@@ -652,26 +652,34 @@ __device__ __forceinline__ SpanGeom span_geom(const float* __restrict__ s, int2 
 
 // tiles [tx0, tx0 + len) of tile row ty that the splat can touch (within its box).  NOT inlined:
 // tile_count and tile_emit must execute the very same instructions (fp contraction differs
-// between inlining contexts) or their per-row lengths could disagree.
-__device__ __attribute__((noinline)) void row_span(const SpanGeom& g, int ty, int tile_size, int H, int& tx0, int& len) {
-    if (!g.exact) { tx0 = g.x0; len = g.x1 - g.x0; return; }
+// between inlining contexts) or their per-row lengths could disagree.  Everything travels in registers (scalars in,
+// tx0 | len << 16 out): a struct or an output passed by reference lives on the stack of a non-inlined call, and scratch loads in
+// the row loop of the wave-granular emit cost more than the arithmetic.
+__device__ __attribute__((noinline)) uint32_t row_span_packed(float mx, float my, float A, float B, float C, float tau2,
+                                                              int x0, int x1, int exact, int ty, int tile_size, int H) {
+    if (!exact) return (uint32_t)x0 | ((uint32_t)(x1 - x0) << 16);
     const float ts = (float)tile_size;
     float ylo = (float)ty * ts + 0.5f, yhi = fminf((float)ty * ts + ts - 0.5f, (float)H - 0.5f);
-    float det = g.A * g.C - g.B * g.B;
-    float Ymax = sqrtf(g.tau2 * g.A / det) * 1.001f + 0.02f;
-    float lo = fmaxf(g.my - yhi, -Ymax), hi = fminf(g.my - ylo, Ymax);       // dy = my - y
-    if (!(lo <= hi)) { tx0 = g.x0; len = 0; return; }
-    float dstar = g.B * sqrtf(g.tau2 / (det * g.C));                          // dy of the rightmost point
+    float det = A * C - B * B;
+    float Ymax = sqrtf(tau2 * A / det) * 1.001f + 0.02f;
+    float lo = fmaxf(my - yhi, -Ymax), hi = fminf(my - ylo, Ymax);       // dy = my - y
+    if (!(lo <= hi)) return (uint32_t)x0;
+    float dstar = B * sqrtf(tau2 / (det * C));                          // dy of the rightmost point
     float dyR = fminf(fmaxf(dstar, lo), hi), dyL = fminf(fmaxf(-dstar, lo), hi);
-    float rA = 1.f / g.A;
-    float eR = (g.B * dyR + sqrtf(fmaxf(g.tau2 * g.A - det * dyR * dyR, 0.f))) * rA;   // px - mx, right end
-    float eL = (g.B * dyL - sqrtf(fmaxf(g.tau2 * g.A - det * dyL * dyL, 0.f))) * rA;   // left end
-    float xR = g.mx + eR + fabsf(eR) * 1e-3f + 0.02f;
-    float xL = g.mx + eL - fabsf(eL) * 1e-3f - 0.02f;
-    int a = max((int)ceilf((xL - (ts - 0.5f)) / ts), g.x0);       // pixel centres of tile t: 16t+0.5 .. 16t+15.5
-    int b = min((int)floorf((xR - 0.5f) / ts), g.x1 - 1);
-    tx0 = a;
-    len = max(0, b - a + 1);
+    float rA = 1.f / A;
+    float eR = (B * dyR + sqrtf(fmaxf(tau2 * A - det * dyR * dyR, 0.f))) * rA;   // px - mx, right end
+    float eL = (B * dyL - sqrtf(fmaxf(tau2 * A - det * dyL * dyL, 0.f))) * rA;   // left end
+    float xR = mx + eR + fabsf(eR) * 1e-3f + 0.02f;
+    float xL = mx + eL - fabsf(eL) * 1e-3f - 0.02f;
+    int a = max((int)ceilf((xL - (ts - 0.5f)) / ts), x0);       // pixel centres of tile t: 16t+0.5 .. 16t+15.5
+    int b = min((int)floorf((xR - 0.5f) / ts), x1 - 1);
+    return (uint32_t)a | ((uint32_t)max(0, b - a + 1) << 16);
+}
+
+__device__ __forceinline__ void row_span(const SpanGeom& g, int ty, int tile_size, int H, int& tx0, int& len) {
+    const uint32_t r = row_span_packed(g.mx, g.my, g.A, g.B, g.C, g.tau2, g.x0, g.x1, g.exact ? 1 : 0, ty, tile_size, H);
+    tx0 = (int)(r & 0xFFFFu);
+    len = (int)(r >> 16);
 }
 
 // ---- block-level row table for the tight path.  A block owns 256 splats; all their tile rows
@@ -964,6 +972,193 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN_cap, const u
     }
 }
 
+// ---- wave-granular chained count + emit for the exact ("tight") path: what the training step and the renderer run.
+// The block-cooperative kernel above spends ~70 % of its wave cycles waiting (SQ_WAIT_ANY): a dozen barriers per block, two
+// dependent binary searches in LDS per emitted key (8 + ~3 steps), 29 KB of LDS = 5 blocks per CU.  Here a WAVE owns 64
+// consecutive depth-sorted splats; nothing is shared between waves but the look-back chain (one status word per wave) and the
+// block's ticket.  The unit of work is the tile ROW of a splat ("item"; items in splat-major order ARE the emission order):
+//   count  lane = item, 64 at a time: owner splat by a 6-step search over the wave's row prefixes, span by row_span_packed
+//          (the same non-inlined arithmetic as every other path); the results of the first WE_CACHE chunks stay in registers;
+//   chain  the wave's total goes through the decoupled look-back;
+//   emit   per 64 items: a wave scan gives every item its first output slot; items with keys are compacted into a 64-entry
+//          table and set ONE bit per item in a bitmap of the chunk's output slots (ds_or_b64); every 64 outputs are then
+//          resolved with one broadcast read of the bitmap word + a popcount (rank = number of item starts at or before the
+//          slot), no search, and stored coalesced.
+// There is no row pool and therefore no slow list: a 68-row splat is just 68 items.  No barrier after the ticket, 4.6 KB of LDS
+// per wave.  A first wave-granular version with lane = splat (8 rows in registers, taller splats on the slow list) needed
+// 9.7e7 VALU instructions (the block kernel: 5.3e7) and 316 + 24 us; kept out of the tree.
+// Same output, bit for bit, as the two-phase path: tests/test_gpu_parity.py::test_fused_binning_equals_the_two_phase_path,
+// tests/test_gpu_configs.py (15 - 40 M keys).
+constexpr int WE_WAVES = 16;              // waves per block = 64-splat chunks per ticket
+constexpr int WE_CACHE = 6;               // item chunks whose spans stay in registers between count and emit (384 rows)
+constexpr int WE_GROUPS = 128;            // bitmap words per item chunk: 64 items x at most 128 tile columns / 64 (images up to 2 048 px wide; wider ones take the block kernel)
+struct WaveEmitLds {
+    float geo[64][6];                     // mx my A B C tau2
+    uint32_t box[64];                     // x0 | x1 << 16 (tile columns of the bounding box)
+    uint32_t flags[64];                   // y0 | exact << 31
+    uint32_t row_base[65];                // exclusive prefix of the splats' row counts; [64] = the wave's items
+    uint32_t key0[64];                    // camera * tiles + y0 * tw
+    uint32_t id[64];
+    uint32_t cnt[64];                     // keys per splat (tiles_per_gauss, on request)
+    uint32_t it_start[64], it_key[64], it_id[64];       // compacted items of the current chunk
+    unsigned long long bitmap[WE_GROUPS];
+};
+
+__global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
+    uint32_t CN_cap, const uint32_t* __restrict__ n_sorted_ptr, bool radii_in_records, uint32_t N,
+    const uint32_t* __restrict__ sorted_ids, const int32_t* __restrict__ radii, const float* __restrict__ splats, int tile_size,
+    int tw, int th, int H, uint32_t cap, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ flat_ids,
+    unsigned long long* status, uint32_t* chain_counter, uint32_t* chain_err, uint32_t* __restrict__ n_isect_out,
+    uint32_t* __restrict__ tiles_out) {
+    __shared__ WaveEmitLds Lw[WE_WAVES];
+    __shared__ uint32_t s_blk;
+    WaveEmitLds& L = Lw[threadIdx.x >> 6];
+    const int lane = lane_id();
+    // ONE ticket per block of 16 waves = 1 024 splats: a returning atomic on one word saturates near 88 per microsecond
+    // (MI355X_MICROARCH, "dequeue"); a ticket per wave (31 k of them) cost 770 us.  Wave w of ticket b is chain entry
+    // 16 b + w; all 16 run concurrently, so every predecessor of a chain entry belongs to a block that has started and
+    // publishes its aggregate without waiting for anybody.  (Several chunks per wave do NOT work: a wave could publish the
+    // aggregate of its second chunk only after its first chunk's look-back, which serialises the whole chain: 115 ms.)
+    if (threadIdx.x == 0) s_blk = atomicAdd(chain_counter, 1u);
+    __syncthreads();
+    const uint32_t CN = live_count(n_sorted_ptr, CN_cap);
+    const uint32_t wid = s_blk * (uint32_t)WE_WAVES + (threadIdx.x >> 6);
+    if (wid * 64u >= CN) return;              // past the end of the sorted list
+    const uint32_t i = wid * 64u + (uint32_t)lane;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t idx = 0, rows = 0;
+    {
+        SpanGeom geo;
+        geo.mx = geo.my = geo.A = geo.B = geo.C = geo.tau2 = 0.f;
+        geo.x0 = geo.y0 = geo.x1 = geo.y1 = 0;
+        geo.exact = false;
+        uint32_t kc = 0;
+        if (i < CN) {
+            idx = sorted_ids[i];
+            const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
+            int2 r = radii_in_records ? make_int2(__float_as_int(sp[SP_RX]), __float_as_int(sp[SP_RY]))
+                                      : *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
+            if (r.x > 0 && r.y > 0) {
+                geo = span_geom(sp, r, tile_size, tw, th);
+                rows = (uint32_t)(geo.y1 - geo.y0);
+                kc = (idx / N) * (uint32_t)(tw * th);
+            }
+        }
+        L.geo[lane][0] = geo.mx; L.geo[lane][1] = geo.my; L.geo[lane][2] = geo.A;
+        L.geo[lane][3] = geo.B; L.geo[lane][4] = geo.C; L.geo[lane][5] = geo.tau2;
+        L.box[lane] = (uint32_t)geo.x0 | ((uint32_t)geo.x1 << 16);
+        L.flags[lane] = (uint32_t)geo.y0 | (geo.exact ? 0x80000000u : 0u);
+        L.key0[lane] = kc + (uint32_t)(geo.y0 * tw);
+        L.id[lane] = idx;
+        L.cnt[lane] = 0u;
+    }
+    const uint32_t rincl = wave_incl_scan_u32(rows);
+    L.row_base[lane] = rincl - rows;
+    const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+    if (lane == 63) L.row_base[64] = R;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // same-wave LDS hand-off
+    __builtin_amdgcn_wave_barrier();
+
+    // item j -> (owner splat g, tx0 | len << 16)
+    auto eval_item = [&](uint32_t j, uint32_t& g, uint32_t& span) {
+        uint32_t lo = 0, hi = 63;                  // largest g with row_base[g] <= j (splats without rows share a prefix with their successor)
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (L.row_base[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        g = lo;
+        const uint32_t fl = L.flags[lo], bx = L.box[lo];
+        const int ty = (int)(fl & 0x7FFFFFFFu) + (int)(j - L.row_base[lo]);
+        span = row_span_packed(L.geo[lo][0], L.geo[lo][1], L.geo[lo][2], L.geo[lo][3], L.geo[lo][4], L.geo[lo][5],
+                               (int)(bx & 0xFFFFu), (int)(bx >> 16), (int)(fl >> 31), ty, tile_size, H);
+    };
+
+    // ---- count
+    uint32_t c_g[WE_CACHE], c_span[WE_CACHE];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int c = 0; c < WE_CACHE; c++) {
+        c_g[c] = 0; c_span[c] = 0;
+        const uint32_t j = (uint32_t)c * 64u + (uint32_t)lane;
+        if ((uint32_t)c * 64u < R) {               // wave-uniform
+            if (j < R) eval_item(j, c_g[c], c_span[c]);
+            mine += c_span[c] >> 16;
+            if (tiles_out && (c_span[c] >> 16)) atomicAdd(&L.cnt[c_g[c]], c_span[c] >> 16);
+        }
+    }
+    for (uint32_t j0 = (uint32_t)WE_CACHE * 64u; j0 < R; j0 += 64u) {
+        uint32_t g = 0, span = 0;
+        if (j0 + lane < R) eval_item(j0 + (uint32_t)lane, g, span);
+        mine += span >> 16;
+        if (tiles_out && (span >> 16)) atomicAdd(&L.cnt[g], span >> 16);
+    }
+    const uint32_t total = wave_sum_u32(mine);
+    // ---- chain
+    const uint32_t base = chain_lookback(status, wid, total, lane, chain_err);
+    if (wid == (CN - 1u) / 64u && lane == 0) {
+        uint32_t tot = base + total;
+        if (tot > cap) { atomicOr(chain_err, 4u); tot = cap; }
+        *n_isect_out = tot;
+    }
+    if (tiles_out) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i < CN) tiles_out[idx] = L.cnt[lane];
+    }
+    // ---- emit
+    uint32_t running = 0;                            // outputs of the chunks before this one (wave-local)
+    auto emit_chunk = [&](uint32_t j, uint32_t g, uint32_t span) {
+        const uint32_t len = span >> 16;
+        const uint32_t incl = wave_incl_scan_u32(len);
+        const uint32_t Tc = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (Tc == 0u) return;
+        const uint32_t start = incl - len;           // chunk-local first slot of this item
+        const uint32_t ng = (Tc + 63u) >> 6;
+        for (uint32_t w = (uint32_t)lane; w < ng; w += 64u) L.bitmap[w] = 0ull;
+        const bool has = len != 0u;
+        const unsigned long long hb = wave_ballot(has);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has) {
+            const uint32_t ci = (uint32_t)__popcll(hb & lt_mask);
+            const uint32_t row = j - L.row_base[g];
+            L.it_start[ci] = start;
+            L.it_key[ci] = L.key0[g] + row * (uint32_t)tw + (span & 0xFFFFu);
+            L.it_id[ci] = L.id[g];
+            atomicOr(&L.bitmap[start >> 6], 1ull << (start & 63u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t before = 0;                         // item starts in the bitmap words already walked (wave-uniform)
+        const unsigned long long le_mask = lt_mask | (1ull << lane);
+        for (uint32_t w = 0; w < ng; w++) {
+            const unsigned long long m = L.bitmap[w];
+            const uint32_t q = (w << 6) + (uint32_t)lane;
+            if (q < Tc) {
+                const uint32_t rank = before + (uint32_t)__popcll(m & le_mask) - 1u;     // slot 0 of the chunk starts an item: rank >= 0
+                const uint32_t p = base + running + q;
+                if (p < cap) {
+                    tile_keys[p] = L.it_key[rank] + (q - L.it_start[rank]);
+                    flat_ids[p] = L.it_id[rank];
+                }
+            }
+            before += (uint32_t)__popcll(m);
+        }
+        running += Tc;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the tables are rewritten by the next chunk
+        __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll
+    for (int c = 0; c < WE_CACHE; c++)
+        if ((uint32_t)c * 64u < R) emit_chunk((uint32_t)c * 64u + (uint32_t)lane, c_g[c], c_span[c]);
+    for (uint32_t j0 = (uint32_t)WE_CACHE * 64u; j0 < R; j0 += 64u) {
+        uint32_t g = 0, span = 0;
+        if (j0 + lane < R) eval_item(j0 + (uint32_t)lane, g, span);
+        emit_chunk(j0 + (uint32_t)lane, g, span);
+    }
+}
+
 // Emission of the big splats listed by tile_emit_kernel: one wave per splat, waves stride over the list.
 // Lane = tile row: the spans of 64 rows are computed at once and scanned, then the lanes write the keys
 // of those rows side by side.  (Walking the rows from the top for every key, as the first version did
@@ -1068,6 +1263,8 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
 __global__ void clamp_count_kernel(uint32_t* n_isect, uint32_t cap, uint32_t* err) {
     if (*n_isect > cap) { *n_isect = cap; atomicOr(err, 4u); }
 }
+
+int g_emit_mode = 1;
 
 struct BinWs {
     uint32_t *tiles, *dkeys_a, *dkeys_b, *ids_a, *ids_b, *cum, *n_isect, *slow, *tmp;
@@ -1251,15 +1448,21 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     const uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
     // chain state lives in the (unused here) `cum` array: status[nblocks] u64 | counter | err
     uint32_t nblocks = (uint32_t)mi_div_up(CN, 256);
+    const uint32_t nchain = (uint32_t)WE_WAVES * (uint32_t)mi_div_up(CN, 64 * WE_WAVES);   // one status word per 64-splat chunk (>= nblocks)
     unsigned long long* status = reinterpret_cast<unsigned long long*>(ws.cum);
-    uint32_t* counter = ws.cum + 2 * (size_t)nblocks;
+    uint32_t* counter = ws.cum + 2 * (size_t)nchain;
     uint32_t* err = async_err_ptr();
     MI_REQUIRE(err, "bin_tiles: no device error word");
     uint32_t* slow_count = counter + 2;                    // cleared by the same memset as the chain state
-    MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nblocks + 4) * sizeof(uint32_t), st));
+    MI_HIP(hipMemsetAsync(ws.cum, 0, ((size_t)2 * nchain + 4) * sizeof(uint32_t), st));
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
-    if (tight)
+    const bool wave_emit = tight && g_emit_mode == 1 && tile_width <= WE_GROUPS;
+    if (wave_emit)
+        MI_LAUNCH("tile_emit", tile_emit_wave_kernel, dim3(mi_div_up(CN, 64 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
+                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    else if (tight)
         MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, ws.slow, slow_count);
@@ -1267,7 +1470,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
         MI_LAUNCH("tile_emit", (tile_emit_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt, nullptr, nullptr);
-    if (tight)
+    if (tight && !wave_emit)
         MI_LAUNCH("tile_emit_slow", tile_emit_slow_kernel, dim3(SLOW_BLOCKS), dim3(256), 0, st, ws.slow, slow_count, tile_size,
                   tile_width, height, cap, tk, fi);
     MI_LAUNCH_CHECK();
@@ -1321,6 +1524,12 @@ extern "C" int mi3dgs_async_errors(uint32_t* out, int reset) {
         uint32_t z = 0;
         MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_async_err), &z, sizeof(z)));
     }
+    return 0;
+}
+
+// A/B switch: 1 (default) = wave-granular chained emit (tile_emit_wave_kernel), 0 = the block-cooperative one of round 1.
+extern "C" int mi3dgs_debug_set_emit_mode(int mode) {
+    g_emit_mode = mode ? 1 : 0;
     return 0;
 }
 

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_debug_set_sort_mode": (_i, [_i]),
     "mi3dgs_debug_set_raster_mode": (_i, [_i]),
+    "mi3dgs_debug_set_emit_mode": (_i, [_i]),
     "mi3dgs_async_errors": (_i, [C.POINTER(_u32), _i]),
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_scan_exclusive_u32": (_i, [_f, _f, _ll, _f, _f, _sz, _f]),
@@ -91,6 +92,11 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         if handle.mi3dgs_abi_version() != 3:
             raise Mi3dgsError("libmi3dgs.so ABI version mismatch")
+        # A/B switches for measurements (defaults are the product path): MI3DGS_EMIT_MODE, MI3DGS_RASTER_MODE, MI3DGS_SORT_MODE
+        for env, fn in (("MI3DGS_EMIT_MODE", "mi3dgs_debug_set_emit_mode"), ("MI3DGS_RASTER_MODE", "mi3dgs_debug_set_raster_mode"),
+                        ("MI3DGS_SORT_MODE", "mi3dgs_debug_set_sort_mode")):
+            if os.environ.get(env) is not None:
+                getattr(handle, fn)(int(os.environ[env]))
         _lib = handle
     return _lib
 
