@@ -190,8 +190,8 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
                          void* stream);
 
 /* A/B switch: 1 (default) = the rasterisers whose pixel x splat quadratic forms run on the matrix pipe
- * (v_mfma_f32_32x32x2_f32, csrc/rasterize_mfma.hip), 0 = the round-1 all-VALU kernels.  Forward and
- * backward must run in the same mode. */
+ * (v_mfma_f32_32x32x2_f32, csrc/rasterize_mfma.hip), 0 = the round-1 all-VALU kernels, 2 = as 1 with the tile list
+ * fetched one batch ahead (measured slower).  Forward and backward must run in the same mode (0 vs 1/2). */
 int mi3dgs_debug_set_raster_mode(int mode);
 
 /* ---- loss ----------------------------------------------------------------------------

@@ -71,18 +71,28 @@ struct Staged {
     float4 uni[BLOCK + 1];               // per splat, wave-uniform in the chain: r, g, b (read one visit ahead)
 };
 
-__device__ __forceinline__ void stage_splat(Staged& L, int slot, bool live, const float* __restrict__ rec_f, float xc,
-                                            float yc) {
+// A splat record as the rasterisers use it: fetched one batch AHEAD of its use (the loads of batch b + 1 are issued
+// before batch b is composited; a tile's list is walked in batches of 256 and the gather used to sit, fully exposed,
+// between two barriers at the head of every batch: 38 - 40 % of both kernels' wave cycles were SQ_WAIT_ANY).
+struct RecRegs { float4 a, bb; float cb; };      // x y A B | C o r g | b;  o = 0: padding
+
+__device__ __forceinline__ RecRegs load_rec(const float* __restrict__ splats, int id) {
+    RecRegs r;
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.bb = r.a; r.cb = 0.f;
+    if (id >= 0) {
+        const float* rec_f = splats + (size_t)id * SPLAT_STRIDE;
+        const float4* rec = reinterpret_cast<const float4*>(rec_f);
+        r.a = rec[0]; r.bb = rec[1]; r.cb = rec_f[SP_B];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void stage_splat(Staged& L, int slot, const RecRegs& r, float xc, float yc) {
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-        const float4* rec = reinterpret_cast<const float4*>(rec_f);
-        const float4 a = rec[0], bb = rec[1];                 // x y A B | C o r g
-        const float cb = rec_f[SP_B];
-        if (bb.y > 0.f) {
-            quad_coefs(a.x, a.y, a.z, a.w, bb.x, bb.y, xc, yc, c);
-            u = make_float4(bb.z, bb.w, cb, 0.f);
-        }
+    if (r.bb.y > 0.f) {
+        quad_coefs(r.a.x, r.a.y, r.a.z, r.a.w, r.bb.x, r.bb.y, xc, yc, c);
+        u = make_float4(r.bb.z, r.bb.w, r.cb, 0.f);
     }
     const int sb = slot >> 5, row = slot & 31;
 #pragma unroll
@@ -177,7 +187,7 @@ __device__ __forceinline__ float alpha_of(float s) {
     return __builtin_amdgcn_exp2f(__builtin_fminf(s, LOG2_MAX_ALPHA));
 }
 
-template <bool HAS_BG>
+template <bool HAS_BG, bool PREFETCH>
 __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
@@ -201,12 +211,23 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int cur = 0;
     unsigned long long live = wave_ballot(inside);            // lanes still compositing
+    // ids two batches ahead, records one batch ahead (the record address depends on the id)
+    const int i0 = start + (int)threadIdx.x;
+    RecRegs rec_next = load_rec(splats, i0 < end ? flatten_ids[i0] : -1);
+    int id_next = i0 + BLOCK < end ? flatten_ids[i0 + BLOCK] : -1;
     for (int bs = start; bs < end; bs += BLOCK) {
         if (!__syncthreads_or(live != 0ull)) break;
-        const int idx = bs + (int)threadIdx.x;
-        const bool in_list = idx < end;
-        stage_splat(L, (int)threadIdx.x, in_list, splats + (size_t)(in_list ? flatten_ids[idx] : 0) * SPLAT_STRIDE, xc, yc);
+        if (!PREFETCH) {          // A/B: the gather between the two barriers, as before
+            const int i1 = bs + (int)threadIdx.x;
+            rec_next = load_rec(splats, i1 < end ? flatten_ids[i1] : -1);
+        }
+        stage_splat(L, (int)threadIdx.x, rec_next, xc, yc);
         __syncthreads();
+        if (PREFETCH) {
+            rec_next = load_rec(splats, id_next);
+            const int i2 = bs + 2 * BLOCK + (int)threadIdx.x;
+            id_next = i2 < end ? flatten_ids[i2] : -1;
+        }
         const int bsz = min(BLOCK, end - bs);
         for (int sb = 0; sb * SUB < bsz; sb++) {
             if (live == 0ull) break;
@@ -316,7 +337,7 @@ __device__ __forceinline__ void bwd_sub_batch(StagedBwd& L, const float (&s)[SUB
     }
 }
 
-template <bool HAS_BG, bool ABSGRAD>
+template <bool HAS_BG, bool ABSGRAD, bool PREFETCH>
 __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
@@ -377,26 +398,36 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     float T = T_final;
     float bufdot = 0.f;                         // (colour accumulated behind the current splat) . v_rgb
     const unsigned long long has = wave_ballot(bin_final >= 0);
+    // ids two batches ahead, records one batch ahead (slot k of a batch <-> sorted index be - k)
+    const int j0 = bmax - (int)threadIdx.x;
+    int id_cur = j0 >= start ? flatten_ids[j0] : -1;
+    RecRegs rec_next = load_rec(splats, id_cur);
+    int id_next = j0 - BLOCK >= start ? flatten_ids[j0 - BLOCK] : -1;
     for (int be = bmax; be >= start; be -= BLOCK) {
-        // slot k <-> sorted index be - k: rows of a sub-batch run back to front
-        const int idx = be - (int)threadIdx.x;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < AC_STRIDE; k++) L.acc[threadIdx.x][k] = 0.f;
+        if (!PREFETCH) {          // A/B: the gather between the two barriers, as before
+            const int j1 = be - (int)threadIdx.x;
+            id_cur = j1 >= start ? flatten_ids[j1] : -1;
+            rec_next = load_rec(splats, id_cur);
+        }
         {
-            const bool in_list = idx >= start;
-            const int id = in_list ? flatten_ids[idx] : 0;
-            const float* rec_f = splats + (size_t)id * SPLAT_STRIDE;
-            stage_splat(L.f, (int)threadIdx.x, in_list, rec_f, xc, yc);
-            if (in_list) {
-                const float4* rec = reinterpret_cast<const float4*>(rec_f);
-                const float4 a = rec[0], bb = rec[1];
+            stage_splat(L.f, (int)threadIdx.x, rec_next, xc, yc);
+            if (id_cur >= 0) {
+                const float4 a = rec_next.a, bb = rec_next.bb;
                 L.geo[threadIdx.x] = make_float4(a.x - xc, a.y - yc, a.z, a.w);
                 L.geo2[threadIdx.x] = make_float2(bb.x, bb.y > 0.f ? 1.f / bb.y : 0.f);
-                L.id[threadIdx.x] = id;
+                L.id[threadIdx.x] = id_cur;
             }
         }
         __syncthreads();
+        if (PREFETCH) {
+            id_cur = id_next;
+            rec_next = load_rec(splats, id_next);
+            const int j2 = be - 2 * BLOCK - (int)threadIdx.x;
+            id_next = j2 >= start ? flatten_ids[j2] : -1;
+        }
         const int bsz = min(BLOCK, be - start + 1);
         const int k0 = max(0, be - wmax);            // wave-uniform: nothing in this wave is live before slot k0
         for (int sb = k0 / SUB; sb * SUB < bsz; sb++) {
@@ -450,14 +481,14 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
-                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st) {
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, int prefetch, hipStream_t st) {
     using namespace mfma_raster;
-    if (backgrounds)
-        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
-                  tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids);
-    else
-        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
-                  tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids);
+#define LAUNCH_FWD(BG, PF)                                                                                                \
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG, PF>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids)
+    if (backgrounds) { if (prefetch) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); }
+    else { if (prefetch) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false); }
+#undef LAUNCH_FWD
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -465,14 +496,16 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, hipStream_t st) {
+                          const float* v_alphas, int absgrad, float* v_splats, int prefetch, hipStream_t st) {
     using namespace mfma_raster;
-#define LAUNCH_BWD(BG, AG)                                                                                             \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
-              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,    \
+#define LAUNCH_BWD(BG, AG, PF)                                                                                             \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, PF>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats)
-    if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
-    else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+#define LAUNCH_BWD2(BG, AG) do { if (prefetch) LAUNCH_BWD(BG, AG, true); else LAUNCH_BWD(BG, AG, false); } while (0)
+    if (backgrounds) { if (absgrad) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
+    else { if (absgrad) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
+#undef LAUNCH_BWD2
 #undef LAUNCH_BWD
     MI_LAUNCH_CHECK();
     return 0;

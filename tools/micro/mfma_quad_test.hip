@@ -17,7 +17,7 @@ __global__ __launch_bounds__(BLOCK) void probe(const float* splats, int tx, int 
     __shared__ Staged L;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const float xc = tx * 16 + 8.f, yc = ty * 16 + 8.f;
-    stage_splat(L, threadIdx.x, true, splats + threadIdx.x * SPLAT_STRIDE, xc, yc);
+    stage_splat(L, threadIdx.x, load_rec(splats, (int)threadIdx.x), xc, yc);
     __syncthreads();
     const Basis b = make_basis(wv, lane);
     int lx, ly;
