@@ -324,8 +324,9 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           const float* v_alphas, int absgrad, float* v_splats, int prefetch, hipStream_t st);
 static int g_raster_mode = 1;
 extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
-    // 0 = round-1 VALU kernels, 1 = MFMA (default), 2 = MFMA + the tile list fetched one batch ahead (measured slower: forward
-    // 136.6 -> 149.5 us, backward unchanged, same box; the other blocks of a CU already hide the gather)
+    // 0 = round-1 VALU kernels, 1 = MFMA (default), 2 = A/B variants that were measured slower on the same box and stay off:
+    // forward with the next sub-batch's MFMAs issued before the current one is composited (137 -> 173 us: 96 instead of 64
+    // VGPRs), backward with the tile list fetched one batch ahead (no change; in the forward 136.6 -> 149.5 us)
     g_raster_mode = (mode < 0 || mode > 2) ? 1 : mode;
     return 0;
 }

@@ -137,6 +137,38 @@ __device__ __forceinline__ Basis make_basis(int wave, int lane) {
 
 // log2 alpha (opacity folded in, NOT yet clamped) of this lane's pixel against the 32 splats of sub-batch
 // `sb`: s[i] for row i in depth order.
+struct Acc2 { f16v X, Y; };
+
+// the six MFMAs of a sub-batch, issued; their results are not touched here, so the caller can put independent work behind them
+__device__ __forceinline__ Acc2 issue_sub_batch(const Staged& L, int sb, int lane, const Basis& b) {
+    const int h = lane >> 5, row = lane & 31;
+    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
+    Acc2 r;
+    r.X = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    r.Y = r.X;
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], r.Y, 0, 0, 0);
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], r.Y, 0, 0, 0);
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], r.Y, 0, 0, 0);
+    return r;
+}
+
+// the 16 swaps that give every lane its own pixel's 32 rows (see eval_sub_batch)
+__device__ __forceinline__ void finish_sub_batch(const Acc2& acc, float s[SUB]) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float xv = acc.X[r], yv = acc.Y[r];
+        auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xv), __builtin_bit_cast(unsigned, yv),
+                                                   false, false);
+        const unsigned x_new = sw[0], y_new = sw[1];
+        const int row0 = (r & 3) + 8 * (r >> 2);
+        s[row0] = __builtin_bit_cast(float, x_new);
+        s[row0 + 4] = __builtin_bit_cast(float, y_new);
+    }
+}
+
 __device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane, const Basis& b, float s[SUB]) {
     const int h = lane >> 5, row = lane & 31;
     const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
@@ -187,7 +219,7 @@ __device__ __forceinline__ float alpha_of(float s) {
     return __builtin_amdgcn_exp2f(__builtin_fminf(s, LOG2_MAX_ALPHA));
 }
 
-template <bool HAS_BG, bool PREFETCH>
+template <bool HAS_BG, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
@@ -211,28 +243,29 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int cur = 0;
     unsigned long long live = wave_ballot(inside);            // lanes still compositing
-    // ids two batches ahead, records one batch ahead (the record address depends on the id)
-    const int i0 = start + (int)threadIdx.x;
-    RecRegs rec_next = load_rec(splats, i0 < end ? flatten_ids[i0] : -1);
-    int id_next = i0 + BLOCK < end ? flatten_ids[i0 + BLOCK] : -1;
     for (int bs = start; bs < end; bs += BLOCK) {
         if (!__syncthreads_or(live != 0ull)) break;
-        if (!PREFETCH) {          // A/B: the gather between the two barriers, as before
+        {
+            // (fetching the list one batch ahead was measured: forward 136.6 -> 149.5 us on the same box; the other
+            // blocks of the CU already hide this gather)
             const int i1 = bs + (int)threadIdx.x;
-            rec_next = load_rec(splats, i1 < end ? flatten_ids[i1] : -1);
+            stage_splat(L, (int)threadIdx.x, load_rec(splats, i1 < end ? flatten_ids[i1] : -1), xc, yc);
         }
-        stage_splat(L, (int)threadIdx.x, rec_next, xc, yc);
         __syncthreads();
-        if (PREFETCH) {
-            rec_next = load_rec(splats, id_next);
-            const int i2 = bs + 2 * BLOCK + (int)threadIdx.x;
-            id_next = i2 < end ? flatten_ids[i2] : -1;
-        }
         const int bsz = min(BLOCK, end - bs);
+        Acc2 acc_next;
+        if (PIPE) acc_next = issue_sub_batch(L, 0, lane, basis);
         for (int sb = 0; sb * SUB < bsz; sb++) {
             if (live == 0ull) break;
             float s[SUB];
-            eval_sub_batch(L, sb, lane, basis, s);
+            if (PIPE) {
+                // the MFMAs of sub-batch sb + 1 go out before sub-batch sb is composited: their 3 x 64-cycle dependent
+                // chain then runs behind ~1 000 cycles of vector work instead of in front of it
+                finish_sub_batch(acc_next, s);
+                if ((sb + 1) * SUB < bsz) acc_next = issue_sub_batch(L, sb + 1, lane, basis);
+            } else {
+                eval_sub_batch(L, sb, lane, basis, s);
+            }
             const lds_f4_ptr uni = opaque_lds_base(&L.uni[sb * SUB]);
             Rgb col_next = lds_rgb(uni, 0);
 #pragma unroll
