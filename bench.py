@@ -377,7 +377,8 @@ def main():
                 # HBM bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
                 # separate runs of this command, gfx950 correction applied; tools/profile_round.sh).  NOT measured
                 # in this run: `traffic_source` says so.  Default workload only.
-                return pmc_tab.get(tag.split("/")[0], {}).get("hbm_bytes_per_launch")
+                k = tag.split("/")[0]
+                return (pmc_tab.get(k) or pmc_tab.get(k + "_wave") or {}).get("hbm_bytes_per_launch")
 
             traffic = offline_traffic(dom)
             common = dict(kernel=dom, traffic=traffic,
