@@ -321,13 +321,14 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int prefetch, hipStream_t st);
+                          const float* v_alphas, int absgrad, float* v_splats, int variant, hipStream_t st);
 static int g_raster_mode = 1;
 extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
     // 0 = round-1 VALU kernels, 1 = MFMA (default), 2 = A/B variants that were measured slower on the same box and stay off:
     // forward with the next sub-batch's MFMAs issued before the current one is composited (137 -> 173 us: 96 instead of 64
-    // VGPRs), backward with the tile list fetched one batch ahead (no change; in the forward 136.6 -> 149.5 us)
-    g_raster_mode = (mode < 0 || mode > 2) ? 1 : mode;
+    // VGPRs), backward with the tile list fetched one batch ahead (no change; in the forward 136.6 -> 149.5 us),
+    // 3 = MFMA forward, backward with the cross-lane reduce-scatter instead of the MFMA contraction
+    g_raster_mode = (mode < 0 || (mode > 3 && (mode < 11 || mode > 13))) ? 1 : mode;     // 11..13: timing experiments
     return 0;
 }
 
@@ -369,7 +370,7 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
     if (g_raster_mode != 0)
         return mi_rasterize_bwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
                                      n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats,
-                                     g_raster_mode == 2, st);
+                                     g_raster_mode == 1 ? 0 : g_raster_mode >= 10 ? g_raster_mode : g_raster_mode == 2 ? 2 : 1, st);
 #define LAUNCH_BWD(BG, AG)                                                                                            \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,   \
                        tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas,     \

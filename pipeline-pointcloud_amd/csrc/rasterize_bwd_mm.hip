@@ -1,0 +1,394 @@
+// Backward tile rasteriser with the per-splat pixel sums contracted on the matrix pipe (bf16 MFMA, two-term split).
+// gfx950 only.  Replaces gsplat rasterize_to_pixels_bwd, reached by the reference only through
+// main.py:1312 / main.py:1343.  Built with -fno-slp-vectorize (see the Makefile).
+#include "rasterize_mfma.h"
+
+namespace mfma_raster {
+
+// ---------------------------------------------------------------------------------------- backward, contraction on MFMA
+// The per-splat sums over the pixels of a quadrant ARE a matrix product,
+//     [Q | W] (splats x 64 pixels)  .  [u v u^2 uv v^2 1 | v_r v_g v_b] (64 pixels x 9),
+// with Q = q(s, p) = -dL/dsigma and W = alpha T (the colour weight): moments in columns 0..5, colour sums in 6..8.
+// The chain produces Q and W with lane = pixel, the A operand of an MFMA wants lane = row (splat) with K (pixels)
+// inside the lane, so a wave transposes through a private LDS region: each visit stores its two values as rows
+// (one 32-bit word per pixel), after CH splats the wave reads the 16 rows back as A operands (4 x ds_read_b128 per lane).
+//
+// Which MFMA.  The f32-input forms do NOT run beside the vector pipe: tools/micro/mfma_valu_overlap.hip, one wave of
+// v_mfma_f32_16x16x4_f32 and one wave of v_fma_f32 on the same SIMD take the SUM of their times (5 929 us against 4 372 +
+// 1 797), and the f32 contraction (64 MFMAs = 2 048 cycles per 32 visits) made this kernel slower, 500 -> 750 us.  The bf16
+// forms do overlap and are 16 x cheaper, so the values go through the matrix pipe as TWO bf16 terms each: a word holds
+// hi = the top 16 bits of the f32 (an exact split) and lo = bf16(value - hi) (round to nearest), and the K index of the
+// MFMA is (pixel, part): both parts of a pixel multiply the same basis value, so sum_k A[k] B[k] = sum_p (hi_p + lo_p) b(p)
+// with no unpacking.  16 significant bits per term (relative error <= 2^-16, unbiased), f32 accumulation.  The basis values
+// (half-integers up to 7.5, their products up to 56.25) are exact in bf16; v_rgb gets the same two-term split as two column
+// groups (6..8 hi, 9..11 lo) whose sums land on the same three slots.  4 x v_mfma_f32_16x16x32_bf16 (64 matrix-pipe cycles)
+// per chunk replace the five moment multiplies and the 24-instruction cross-lane reduce-scatter of every live visit.
+// With ABSGRAD the two |.| sums ride along as two more rows per splat (chunks of 4).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+constexpr int TR_STRIDE = 68;
+constexpr int TR_ROWS = 16;
+constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
+// columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums, then |x|, |y|
+constexpr int AW_ABSX = 12, AW_ABSY = 13;       // 9..11: the lo colour sums
+
+// LDS float atomics are lane-serial on this part (tools/micro/lds_ops.hip: ds_add_f32 takes ~3 LDS cycles per ACTIVE lane,
+// 55 for the 18 lanes that would add a chunk's sums, against 3 for a plain ds_write_b32), so every wave keeps its own sums
+// (plain stores, each (wave, slot, column) written at most once per group) and the flush adds the four quadrants.
+template <bool ABSGRAD>
+struct StagedBwdMM {
+    static constexpr int AW = ABSGRAD ? 14 : 12;
+    Staged f;
+    float4 geo[BLOCK];        // mx, my (relative to the tile centre), A, B
+    float2 geo2[BLOCK];       // C, 1 / o
+    int id[BLOCK];
+    float accw[4][GRP][AW];
+    unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (value, splat of the chunk), columns = the wave's 64 pixels
+    unsigned long long gmask[4];        // per wave: slots of the current group whose visit was live (its sums are meaningful)
+    int wave_max[4];
+};
+
+// what a lane does with the accumulator of a chunk: D row 4 (lane >> 4) + r, column lane & 15
+struct MMLane {
+    u4v bop[4];               // B operand of MFMA m: column (lane & 15) at the pixels 16 m + 4 (lane >> 4) + 0..3, both parts
+    int acc_off;              // float offset of this lane's (first row, column) inside a chunk of accw, or -1: nothing to store
+};
+
+__device__ __forceinline__ unsigned f32_hi(float v) { return __builtin_bit_cast(unsigned, v) & 0xFFFF0000u; }
+
+// two values -> two words (hi | lo)
+__device__ __forceinline__ void split2(float a, float b, unsigned& wa, unsigned& wb) {
+    const unsigned ha = f32_hi(a), hb = f32_hi(b);
+    const f2v r = {a - __builtin_bit_cast(float, ha), b - __builtin_bit_cast(float, hb)};
+    const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v));      // v_cvt_pk_bf16_f32
+    wa = ha | (l & 0xFFFFu);
+    wb = hb | (l >> 16);
+}
+
+// The contraction of a chunk is software-pipelined against the visits of the NEXT chunk: its A operands are read when its last
+// visit has stored (LDS executes a wave's instructions in order, so the next chunk's stores to the same rows stay behind these
+// reads), its 4 MFMAs are issued one per visit between the vector instructions of the following visits, and its
+// sums are stored when that chunk ends.  At a sub-batch boundary a pending chunk has its operands and none of its MFMAs.
+struct MMPend {
+    u4v a[4];
+    f4v d;
+    int slot0;                // first slot of the chunk inside its group
+    bool on;                  // wave-uniform
+};
+
+__device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
+    P.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, P.a[m]), __builtin_bit_cast(bf8v, mm.bop[m]), P.d, 0, 0, 0);
+}
+
+template <bool ABSGRAD>
+__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv) {
+    constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
+    if (mm.acc_off >= 0) {
+        float* a = &L.accw[wv][P.slot0][0] + mm.acc_off;
+        a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3];
+    }
+    P.on = false;
+}
+
+template <bool ABSGRAD>
+__device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int wv, int lane, int slot0) {
+    asm volatile("" ::: "memory");      // the rows were written by other lanes of this wave: LDS is in order per wave
+    const u4v* ap = reinterpret_cast<const u4v*>(&L.tr[wv][lane & 15][4 * (lane >> 4)]);
+    P.a[0] = ap[0]; P.a[1] = ap[4]; P.a[2] = ap[8]; P.a[3] = ap[12];
+    asm volatile("" ::: "memory");      // the next chunk's stores stay behind these reads
+    P.d = f4v{0.f, 0.f, 0.f, 0.f};
+    P.slot0 = slot0;
+    P.on = true;
+}
+
+template <bool ABSGRAD>
+__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv) {
+    if (!P.on) return;
+#pragma unroll
+    for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
+    mm_finish(L, P, mm, wv);
+}
+
+// One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
+// FAST: every pixel of the wave that composited anything is already in range (index <= its last contributor).
+// gbit0: bit of this sub-batch's first chunk in the group's mask.
+template <bool ABSGRAD, bool FAST, int EXP>
+__device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
+                                                 int bin_final, unsigned long long has, const PixelBasis& px, const MMLane& mm,
+                                                 MMPend& P, unsigned long long& gmask, const float (&vrgb)[3], float tail,
+                                                 float& T, float& bufdot) {
+    constexpr int CH = ABSGRAD ? 4 : 8;          // splats per chunk: CH x (2 or 4 values) = 16 rows
+    const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
+    const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
+    // colours two visits ahead: LDS serves a wave in order, so a read queues behind the two stores of the visit before it
+    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, 1);
+    unsigned* trw = &L.tr[wv][0][lane];
+    // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
+    // bookkeeping counts like vector work.  A dead visit is a compare and a branch: its rows keep whatever they held, the
+    // contraction is row-wise (garbage in row r only reaches sums of row r), and the flush takes a (wave, slot) sum only if
+    // the visit was live (`gmask`, one bit per slot of the group).
+    unsigned live = 0u;                          // bits of this sub-batch
+#pragma unroll
+    for (int i = 0; i < SUB; i++) {
+        const int k = sb * SUB + i;
+        const int ci = i % CH;
+        const Rgb col = (EXP & 2) ? Rgb{0.3f, 0.4f, 0.5f} : col_next;
+        if (!(EXP & 2)) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
+        if (ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
+        // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
+        unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
+        if (!FAST) valid &= mask_ge_i(bin_final, be - k);
+        if (valid != 0ull) {
+            live |= 1u << i;
+            const float alpha = alpha_of(s[i]);
+            // branch-free live part: a lane that does not take part runs it with alpha = 0 (ra = 1, T and bufdot
+            // unchanged bit for bit, both rows 0)
+            const float a_eff = lane_of(valid) ? alpha : 0.f;
+            const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+            T *= ra;
+            const float fac = a_eff * T;
+            const float cv = col.x * vrgb[0] + col.y * vrgb[1] + col.z * vrgb[2];            // c . v_rgb
+            const float v_alpha = T * cv - ra * (bufdot - tail);
+            bufdot = __builtin_fmaf(cv, fac, bufdot);
+            // q = o vis dL/dalpha = -dL/dsigma; zero where the 0.999 clamp is active (alpha == o vis otherwise)
+            const unsigned long long gon = valid & mask_le(s[i], LOG2_MAX_ALPHA);
+            const float q = lane_of(gon) ? alpha * v_alpha : 0.f;
+            unsigned wq, wf;
+            split2(q, fac, wq, wf);
+            trw[ci * TR_STRIDE] = wq;
+            trw[(CH + ci) * TR_STRIDE] = wf;
+            if (ABSGRAD) {
+                const float4 ge = L.geo[k];
+                const float cC = L.geo2[k].x;
+                const float dx = ge.x - px.u, dy = ge.y - px.v;
+                unsigned wx, wy;
+                split2(fabsf(q * (ge.z * dx + ge.w * dy)), fabsf(q * (ge.w * dx + cC * dy)), wx, wy);
+                trw[(2 * CH + ci) * TR_STRIDE] = wx;
+                trw[(3 * CH + ci) * TR_STRIDE] = wy;
+            }
+        }
+        if (ci == CH - 1) {
+            if (P.on) mm_finish(L, P, mm, wv);
+            if ((live >> (i - (CH - 1))) & ((1u << CH) - 1u)) mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
+        }
+    }
+    gmask |= (unsigned long long)live << gs0;
+}
+
+template <bool HAS_BG, bool ABSGRAD, int EXP>
+__global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
+    constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
+    __shared__ StagedBwdMM<ABSGRAD> L;
+    const int t = blockIdx.x;
+    const int cam = t / (tw * th);
+    const int tile_in = t - cam * (tw * th);
+    const int ty = tile_in / tw, tx = tile_in - ty * tw;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int lx, ly;
+    pixel_of_lane(wv, lane, lx, ly);
+    const int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
+    const bool inside = px_i < W && py_i < H;
+    const float xc = (float)(tx * TILE) + 8.f, yc = (float)(ty * TILE) + 8.f;
+    PixelBasis px;
+    px.u = (float)lx - 7.5f; px.v = (float)ly - 7.5f;
+    px.uu = px.u * px.u; px.uv = px.u * px.v; px.vv = px.v * px.v;
+    const int start = tile_offsets[t];
+    const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+    if (end <= start) return;
+
+    float T_final = 1.f, vr0 = 0.f, vr1 = 0.f, vr2 = 0.f, va = 0.f;
+    int bin_final = -1;
+    if (inside) {
+        const size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        const float al = alphas[pix];
+        T_final = 1.f - al;
+        bin_final = last_ids[pix];
+        vr0 = v_render[3 * pix]; vr1 = v_render[3 * pix + 1]; vr2 = v_render[3 * pix + 2];
+        va = v_alphas[pix];
+        // a pixel that composited nothing has last_id 0 and alpha 0: mark it so that slot `start` is skipped
+        if (al == 0.f) bin_final = -1;
+    }
+    const float vrgb[3] = {vr0, vr1, vr2};
+    float tail = T_final * va;                      // T_final (v_alpha - bg . v_rgb)
+    if (HAS_BG) {
+        const float* bg = backgrounds + 3 * cam;
+        tail -= T_final * (bg[0] * vr0 + bg[1] * vr1 + bg[2] * vr2);
+    }
+    int wmax = bin_final;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    int wmin = bin_final >= 0 ? bin_final : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o, 64));
+    wmin = __builtin_amdgcn_readfirstlane(wmin);
+    if (lane == 0) L.wave_max[wv] = wmax;
+    __syncthreads();
+    const int bmax = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
+    if (bmax < start) return;
+    const Basis basis = make_basis(wv, lane);
+
+    // the B operands of the contraction and this lane's place in its result
+    MMLane mm;
+    {
+        const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            u4v w;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int qx, qy;
+                pixel_of_lane(wv, 16 * m + 4 * g + e, qx, qy);
+                const float u = (float)qx - 7.5f, v = (float)qy - 7.5f;
+                unsigned hb = 0u;                  // bf16 bits
+                if (j < 6) {
+                    const float val = j == 0 ? u : j == 1 ? v : j == 2 ? u * u : j == 3 ? u * v : j == 4 ? v * v : 1.f;
+                    hb = __builtin_bit_cast(unsigned, val) >> 16;          // exact
+                } else if (j < 12) {
+                    const int c = j < 9 ? j - 6 : j - 9;
+                    const int gx = tx * TILE + qx, gy = ty * TILE + qy;
+                    float val = 0.f;
+                    if (gx < W && gy < H) val = v_render[3 * (((size_t)cam * H + gy) * W + gx) + c];
+                    const unsigned hi = f32_hi(val);
+                    if (j < 9) hb = hi >> 16;
+                    else {
+                        const f2v r = {val - __builtin_bit_cast(float, hi), 0.f};
+                        hb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v)) & 0xFFFFu;
+                    }
+                }
+                w[e] = hb | (hb << 16);
+            }
+            mm.bop[m] = w;
+        }
+        // columns of the product: 0..5 moments (AC_QU .. AC_Q), 6..8 colour sums from the hi part of v_rgb, 9..11 from its lo part
+        if (ABSGRAD) {
+            // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3
+            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : (j == 5 ? (g == 2 ? AW_ABSX : AW_ABSY) : -1);
+        } else {
+            // rows: Q 0..7, W 8..15  ->  groups 0, 1 hold Q of splats 4 g + r, groups 2, 3 hold W of splats 4 (g - 2) + r
+            const int col = g < 2 ? (j < 6 ? j : -1) : (j >= 6 && j < 12 ? j : -1);
+            mm.acc_off = col < 0 ? -1 : 4 * (g & 1) * AW + col;
+        }
+    }
+
+    float T = T_final;
+    float bufdot = 0.f;                         // (colour accumulated behind the current splat) . v_rgb
+    const unsigned long long has = wave_ballot(bin_final >= 0);
+    MMPend P;
+    P.on = false;
+    for (int be = bmax; be >= start; be -= BLOCK) {
+        __syncthreads();
+        {
+            const int j1 = be - (int)threadIdx.x;
+            const int id_cur = j1 >= start ? flatten_ids[j1] : -1;
+            const RecRegs rec = load_rec(splats, id_cur);
+            stage_splat(L.f, (int)threadIdx.x, rec, xc, yc);
+            if (id_cur >= 0) {
+                L.geo[threadIdx.x] = make_float4(rec.a.x - xc, rec.a.y - yc, rec.a.z, rec.a.w);
+                L.geo2[threadIdx.x] = make_float2(rec.bb.x, rec.bb.y > 0.f ? 1.f / rec.bb.y : 0.f);
+                L.id[threadIdx.x] = id_cur;
+            }
+        }
+        __syncthreads();
+        const int bsz = min(BLOCK, be - start + 1);
+        const int k0 = max(0, be - wmax);            // wave-uniform: nothing in this wave is live before slot k0
+        for (int g0 = 0; g0 < bsz; g0 += GRP) {      // block-uniform: groups of 64 slots
+            unsigned long long gmask = 0ull;
+#pragma unroll 1
+            for (int sb = g0 / SUB; sb < g0 / SUB + GRP / SUB; sb++) {
+                if (sb * SUB >= bsz || sb < k0 / SUB) continue;
+                float s[SUB];
+                eval_sub_batch(L.f, sb, lane, basis, s);
+                if (be - sb * SUB <= wmin)
+                    bwd_sub_batch_mm<ABSGRAD, true, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot);
+                else
+                    bwd_sub_batch_mm<ABSGRAD, false, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot);
+            }
+            mm_drain(L, P, mm, wv);
+            if (EXP & 1) continue;          // timing experiment: no group barriers, no flush
+            if (lane == 0) L.gmask[wv] = gmask;
+            __syncthreads();
+            // flush: lane -> (slot = lane >> 4, column = lane & 15), 16 slots per round over the block.  A wave's 4 slots lie in
+            // one chunk, so "which quadrants have sums for it" is wave-uniform.  The gradients of (x, y, conic A, B, C, opacity)
+            // follow from the moments about the tile centre:
+            //   sum q dx = mx M - Mu, sum q dx^2 = mx^2 M - 2 mx Mu + Muu, ...   (dx = mx - u, dy = my - v)
+            const unsigned long long m0 = L.gmask[0], m1 = L.gmask[1], m2 = L.gmask[2], m3 = L.gmask[3];
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+#pragma unroll 1
+                for (int rd = 0; rd < GRP / 16; rd++) {
+                    // this wave's four slots of the round: skip it if no quadrant has anything for them
+                    const int sg0 = rd * 16 + 4 * wv;
+                    if ((((m0 | m1 | m2 | m3) >> sg0) & 15ull) == 0ull) continue;
+                    const int sg = sg0 + (lane >> 4);
+                    const int comp = lane & 15;
+                    const int cc = comp < AW ? comp : 0;
+                    float sum = 0.f;
+                    if ((m0 >> sg) & 1ull) sum += L.accw[0][sg][cc];
+                    if ((m1 >> sg) & 1ull) sum += L.accw[1][sg][cc];
+                    if ((m2 >> sg) & 1ull) sum += L.accw[2][sg][cc];
+                    if ((m3 >> sg) & 1ull) sum += L.accw[3][sg][cc];
+                    const int slot = g0 + sg;
+                    const unsigned long long nz = wave_ballot(slot < bsz && comp < AW && sum != 0.f);
+                    const bool touched = ((nz >> (lane & 48)) & 0xFFFFull) != 0ull;
+                    // the other columns of this slot, from the 16 lanes that hold them
+                    const int rb = lane & 48;
+                    const float M = __shfl(sum, rb + AC_Q, 64), Mu = __shfl(sum, rb + AC_QU, 64), Mv = __shfl(sum, rb + AC_QV, 64);
+                    // second operand by output component: x, y none; conic A, B, C their second moments; r, g, b the lo sums
+                    const int xsrc = comp == GR_CA ? AC_QUU : comp == GR_CB ? AC_QUV : comp == GR_CC ? AC_QVV
+                                     : (comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AW_ABSX : comp == GR_ABSY ? AW_ABSY : 0;
+                    const float X = __shfl(sum, rb + xsrc, 64);
+                    if (slot < bsz && touched && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
+                        const float4 ge = L.geo[slot];
+                        const float2 g2 = L.geo2[slot];
+                        const float mx = ge.x, my = ge.y;
+                        const float sdx = mx * M - Mu, sdy = my * M - Mv;                 // sum q dx, sum q dy
+                        float val;
+                        switch (comp) {
+                            case GR_X: val = -(ge.z * sdx + ge.w * sdy); break;
+                            case GR_Y: val = -(ge.w * sdx + g2.x * sdy); break;
+                            case GR_CA: val = -0.5f * (mx * (mx * M - 2.f * Mu) + X); break;
+                            case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + X); break;
+                            case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + X); break;
+                            case GR_OPA: val = M * g2.y; break;
+                            case GR_R: case GR_G: case GR_B: val = sum + X; break;
+                            default: val = X; break;          // |x|, |y|
+                        }
+                        atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace mfma_raster
+
+// experiment: 0 = the product kernel; timing experiments with WRONG results, kept for the measurements quoted in DESIGN.md:
+// bit 0 no group barriers / flush, bit 1 no colour reads (only without background and absgrad)
+int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
+                        const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
+                        const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
+                        const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st) {
+    using namespace mfma_raster;
+#define LAUNCH_MM(BG, AG, E)                                                                                                 \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
+              v_render, v_alphas, v_splats)
+    if (experiment != 0 && !backgrounds && !absgrad) {
+        if (experiment == 1) LAUNCH_MM(false, false, 1);
+        else if (experiment == 2) LAUNCH_MM(false, false, 2);
+        else LAUNCH_MM(false, false, 3);
+    } else if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0); else LAUNCH_MM(true, false, 0); }
+    else { if (absgrad) LAUNCH_MM(false, true, 0); else LAUNCH_MM(false, false, 0); }
+#undef LAUNCH_MM
+    MI_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,202 @@
+// Shared pieces of the MFMA rasterisers (rasterize_mfma.hip: forward and the reduce-scatter backward;
+// rasterize_bwd_mm.hip: the backward with the pixel contraction on the matrix pipe).  gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace mfma_raster {
+
+constexpr int TILE = 16;
+constexpr int BLOCK = TILE * TILE;
+constexpr int SUB = 32;                       // splats per MFMA sub-batch
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LOG2_MAX_ALPHA = -0.0014434169f;   // log2(0.999)
+constexpr float LOG2_ALPHA_THRESHOLD = -7.99435344f;   // log2(1 / 255)
+
+// 64-bit lane masks straight from a compare (no bool round trip), and back: the wave-uniform bookkeeping of the
+// chain (who is still compositing, who hits this splat, who stops here) lives in SGPR pairs on the scalar unit.
+__device__ __forceinline__ unsigned long long mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3 /* oge */); }
+__device__ __forceinline__ unsigned long long mask_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2 /* ogt */); }
+__device__ __forceinline__ unsigned long long mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5 /* ole */); }
+__device__ __forceinline__ unsigned long long mask_ge_i(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 39 /* sge */); }
+__device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---- the six coefficients of log2 alpha over a tile, shared by both kernels.  contract(off) + explicit
+// fma: the two kernels must round identically whatever their surrounding code looks like.
+__device__ __forceinline__ void quad_coefs(float x, float y, float A, float B, float C, float opac, float xc, float yc,
+                                           float c[6]) {
+#pragma clang fp contract(off)
+    const float a = (-0.5f * LOG2E) * A, b = (-LOG2E) * B, cc = (-0.5f * LOG2E) * C;
+    const float mx = x - xc, my = y - yc;          // splat centre relative to the tile centre; d = (mx - u, my - v)
+    c[0] = a;
+    c[1] = b;
+    c[2] = cc;
+    c[3] = -__builtin_fmaf(2.f * a, mx, b * my);
+    c[4] = -__builtin_fmaf(2.f * cc, my, b * mx);
+    const float tq = __builtin_fmaf(b, my, a * mx);
+    c[5] = __builtin_fmaf(mx, tq, (cc * my) * my) + __builtin_amdgcn_logf(opac);     // v_log_f32 = log2
+}
+
+// LDS image of one staged batch of 256 splats
+struct Staged {
+    float coef[BLOCK / SUB][6][SUB];     // A operands: [sub-batch][k][row]
+    float4 uni[BLOCK + 2];               // per splat, wave-uniform in the chain: r, g, b (read one or two visits ahead)
+};
+
+// A splat record as the rasterisers use it: fetched one batch AHEAD of its use (the loads of batch b + 1 are issued
+// before batch b is composited; a tile's list is walked in batches of 256 and the gather used to sit, fully exposed,
+// between two barriers at the head of every batch: 38 - 40 % of both kernels' wave cycles were SQ_WAIT_ANY).
+struct RecRegs { float4 a, bb; float cb; };      // x y A B | C o r g | b;  o = 0: padding
+
+__device__ __forceinline__ RecRegs load_rec(const float* __restrict__ splats, int id) {
+    RecRegs r;
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.bb = r.a; r.cb = 0.f;
+    if (id >= 0) {
+        const float* rec_f = splats + (size_t)id * SPLAT_STRIDE;
+        const float4* rec = reinterpret_cast<const float4*>(rec_f);
+        r.a = rec[0]; r.bb = rec[1]; r.cb = rec_f[SP_B];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void stage_splat(Staged& L, int slot, const RecRegs& r, float xc, float yc) {
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.bb.y > 0.f) {
+        quad_coefs(r.a.x, r.a.y, r.a.z, r.a.w, r.bb.x, r.bb.y, xc, yc, c);
+        u = make_float4(r.bb.z, r.bb.w, r.cb, 0.f);
+    }
+    const int sb = slot >> 5, row = slot & 31;
+#pragma unroll
+    for (int k = 0; k < 6; k++) L.coef[sb][k][row] = c[k];
+    L.uni[slot] = u;
+}
+
+// per-lane basis operands: for the X block lane l supplies basis_{2q + (l >> 5)} of the pixel that lane (l & 31)
+// owns after the swap, for the Y block of the pixel lane 32 + (l & 31) owns.  Basis k: u^2, uv, v^2, u, v, 1.
+__device__ __forceinline__ float basis_of(int k, float u, float v) {
+    switch (k) {
+        case 0: return u * u;
+        case 1: return u * v;
+        case 2: return v * v;
+        case 3: return u;
+        case 4: return v;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ void pixel_of_lane(int wave, int lane, int& lx, int& ly) {
+    lx = ((wave & 1) << 3) + (lane & 7);
+    ly = ((wave >> 1) << 3) + (lane >> 3);
+}
+
+struct Basis { float bx[3], by[3]; };
+
+__device__ __forceinline__ Basis make_basis(int wave, int lane) {
+    Basis b;
+    const int h = lane >> 5;
+    int lx, ly;
+    pixel_of_lane(wave, lane & 31, lx, ly);
+    float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) b.bx[q] = basis_of(2 * q + h, u, v);
+    pixel_of_lane(wave, 32 + (lane & 31), lx, ly);
+    u = (float)lx - 7.5f; v = (float)ly - 7.5f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) b.by[q] = basis_of(2 * q + h, u, v);
+    return b;
+}
+
+// log2 alpha (opacity folded in, NOT yet clamped) of this lane's pixel against the 32 splats of sub-batch
+// `sb`: s[i] for row i in depth order.
+struct Acc2 { f16v X, Y; };
+
+// the six MFMAs of a sub-batch, issued; their results are not touched here, so the caller can put independent work behind them
+__device__ __forceinline__ Acc2 issue_sub_batch(const Staged& L, int sb, int lane, const Basis& b) {
+    const int h = lane >> 5, row = lane & 31;
+    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
+    Acc2 r;
+    r.X = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    r.Y = r.X;
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], r.Y, 0, 0, 0);
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], r.Y, 0, 0, 0);
+    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], r.X, 0, 0, 0);
+    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], r.Y, 0, 0, 0);
+    return r;
+}
+
+// the 16 swaps that give every lane its own pixel's 32 rows (see eval_sub_batch)
+__device__ __forceinline__ void finish_sub_batch(const Acc2& acc, float s[SUB]) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float xv = acc.X[r], yv = acc.Y[r];
+        auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xv), __builtin_bit_cast(unsigned, yv),
+                                                   false, false);
+        const unsigned x_new = sw[0], y_new = sw[1];
+        const int row0 = (r & 3) + 8 * (r >> 2);
+        s[row0] = __builtin_bit_cast(float, x_new);
+        s[row0 + 4] = __builtin_bit_cast(float, y_new);
+    }
+}
+
+__device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane, const Basis& b, float s[SUB]) {
+    const int h = lane >> 5, row = lane & 31;
+    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
+    f16v X = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v Y = X;
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], Y, 0, 0, 0);
+    // register r of a 32x32 accumulator = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  swap(X[r], Y[r]) hands X's
+    // upper-half rows to the lower lanes and Y's lower-half rows to the upper lanes: afterwards, on every lane,
+    // X[r] = row (r & 3) + 8 (r >> 2) and Y[r] = that + 4 of the lane's OWN pixel.
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        // (copy the elements out first: __builtin_bit_cast applied directly to `X[r]` reads element 0 for every r
+        // with this clang)
+        const float xv = X[r], yv = Y[r];
+        auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xv), __builtin_bit_cast(unsigned, yv),
+                                                   false, false);
+        const unsigned x_new = sw[0], y_new = sw[1];
+        const float xr = __builtin_bit_cast(float, x_new), yr = __builtin_bit_cast(float, y_new);
+        const int row0 = (r & 3) + 8 * (r >> 2);
+        s[row0] = xr;
+        s[row0 + 4] = yr;
+    }
+}
+
+// The chain reads one wave-uniform float4 per visit (the splat's colour).  hipcc treats the LDS address as a
+// scalar and re-materialises it into a VGPR for every read (a v_mov per visit in VALU-issue-bound loops); an
+// opaque per-sub-batch VGPR base keeps the row index in the instruction's immediate offset instead.
+struct Rgb { float x, y, z; };
+struct alignas(16) F4pod { float x, y, z, w; };
+typedef __attribute__((address_space(3))) const F4pod* lds_f4_ptr;
+__device__ __forceinline__ lds_f4_ptr opaque_lds_base(const float4* p) {
+    lds_f4_ptr q = (lds_f4_ptr)reinterpret_cast<const F4pod*>(p);
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ Rgb lds_rgb(lds_f4_ptr p, int i) { return Rgb{p[i].x, p[i].y, p[i].z}; }
+
+// alpha of a pair from its log2: min(0.999, o vis).  (sigma is not clamped at 0: a PSD form evaluated through the
+// six-term chain can come out up to ~3e-4 positive in log2 units at the splat centre, i.e. alpha up to 1.0002 o.)
+// The membership test alpha >= 1/255 is taken in the log domain, on the MFMA result itself: a visit that no lane
+// hits costs ONE vector instruction, and forward and backward can not disagree.
+__device__ __forceinline__ float alpha_of(float s) {
+    return __builtin_amdgcn_exp2f(__builtin_fminf(s, LOG2_MAX_ALPHA));
+}
+
+
+// acc row of a staged slot: moments of q = -dL/dsigma about the tile centre, then the colour sums
+constexpr int AC_QU = 0, AC_QV = 1, AC_QUU = 2, AC_QUV = 3, AC_QVV = 4, AC_Q = 5, AC_R = 6, AC_G = 7, AC_B = 8,
+              AC_ABSX = 9, AC_ABSY = 10, AC_STRIDE = 12;
+
+struct PixelBasis { float u, v, uu, uv, vv; };
+
+}  // namespace mfma_raster

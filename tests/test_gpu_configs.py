@@ -410,6 +410,7 @@ def test_forward_and_backward_agree_on_threshold_splats(dev):
     bwd_in = v[0, :, 6] != 0
     assert 0.2 < float(fwd_in.float().mean()) < 0.8                        # the construction straddles the threshold
     assert torch.equal(fwd_in, bwd_in), f"{int((fwd_in != bwd_in).sum())} of {n} threshold splats decided differently"
-    # where both composited it, the backward's alpha is the forward's: colour gradient = alpha * T = render
+    # where both composited it, the backward's alpha is the forward's: colour gradient = alpha * T = render.  The backward carries
+    # alpha * T to its pixel sums as two bf16 terms (16 significant bits, csrc/rasterize_bwd_mm.hip): 2^-16 = 1.5e-5 relative.
     both = fwd_in & bwd_in
-    assert torch.allclose(v[0, :, 6][both], r[0, ..., 0].flatten()[both], rtol=1e-5, atol=0)
+    assert torch.allclose(v[0, :, 6][both], r[0, ..., 0].flatten()[both], rtol=2e-5, atol=0)

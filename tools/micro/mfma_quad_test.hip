@@ -11,6 +11,8 @@ int mi_set_error(const char*, hipError_t, const char*, int) { return 1; }
 int mi_set_error_msg(const char*) { return 1; }
 void mi_prof_begin(const char*, hipStream_t) {}
 void mi_prof_end(hipStream_t) {}
+int mi_rasterize_bwd_mm(int, int, int, int, int, const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float*,
+                        const int32_t*, const float*, const float*, int, float*, int, hipStream_t) { return 1; }
 
 using namespace mfma_raster;
 __global__ __launch_bounds__(BLOCK) void probe(const float* splats, int tx, int ty, float* out /*[256 slots][256 px]*/) {
