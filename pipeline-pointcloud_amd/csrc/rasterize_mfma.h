@@ -39,8 +39,20 @@ __device__ __forceinline__ void quad_coefs(float x, float y, float A, float B, f
 }
 
 // LDS image of one staged batch of 256 splats
+// The quadratic form goes through the matrix pipe as bf16 with every coefficient in THREE bf16 terms (hi and mid are exact
+// truncations, lo is rounded: 24 significant bits) against basis values that are exact in bf16 (half-integers up to 7.5, their
+// products up to 56.25): every product is exact in f32 and the 18 of them are summed in f32, the arithmetic of the f32-input
+// MFMA in another order.  Why not v_mfma_f32_32x32x2_f32, which this file used first: an f32-input MFMA occupies the vector
+// ALUs for its whole duration (tools/micro/mfma_valu_overlap.hip: one wave alternating a 16x16x4 f32 MFMA with six v_fma
+// takes the SUM of both, and a second wave's v_fma gain nothing either), i.e. six of them cost 384 vector cycles per
+// sub-batch; four v_mfma_f32_32x32x16_bf16 take 128 cycles of the matrix pipe, part of them beside vector work.
+// K slots (18 of 32): c0 {hi mid lo} c1 {..} c2 {hi mid | lo} c3 {..} c4 {..} c5 {hi | mid lo}; lanes 0..31 supply slots 0..7 of
+// the first instruction and 16, 17 of the second, lanes 32..63 slots 8..15.
+typedef unsigned qu4 __attribute__((ext_vector_type(4)));
+typedef __bf16 qbf8 __attribute__((ext_vector_type(8)));
 struct Staged {
-    float coef[BLOCK / SUB][6][SUB];     // A operands: [sub-batch][k][row]
+    qu4 coefA[BLOCK / SUB][2][SUB];      // A operand of the first instruction: [sub-batch][lane half][row] = 8 bf16
+    unsigned coefB[BLOCK / SUB][SUB];    // A operand of the second: slots 16, 17 (lanes 0..31; the other 14 slots are zero)
     float4 uni[BLOCK + 2];               // per splat, wave-uniform in the chain: r, g, b (read one or two visits ahead)
 };
 
@@ -60,6 +72,19 @@ __device__ __forceinline__ RecRegs load_rec(const float* __restrict__ splats, in
     return r;
 }
 
+// v = hi + mid + lo in bf16: two exact truncations and a rounded remainder
+__device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+#pragma clang fp contract(off)
+    const unsigned b0 = __builtin_bit_cast(unsigned, v) & 0xFFFF0000u;
+    const float r1 = v - __builtin_bit_cast(float, b0);
+    const unsigned b1 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, b1);
+    const __bf16 l = (__bf16)r2;
+    hi = (unsigned short)(b0 >> 16);
+    mid = (unsigned short)(b1 >> 16);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
 __device__ __forceinline__ void stage_splat(Staged& L, int slot, const RecRegs& r, float xc, float yc) {
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -68,8 +93,14 @@ __device__ __forceinline__ void stage_splat(Staged& L, int slot, const RecRegs& 
         u = make_float4(r.bb.z, r.bb.w, r.cb, 0.f);
     }
     const int sb = slot >> 5, row = slot & 31;
+    unsigned short t[18];
 #pragma unroll
-    for (int k = 0; k < 6; k++) L.coef[sb][k][row] = c[k];
+    for (int k = 0; k < 6; k++) split3(c[k], t[3 * k], t[3 * k + 1], t[3 * k + 2]);
+    if (!(r.bb.y > 0.f)) { t[15] = 0xFF80u; t[16] = 0; t[17] = 0; }        // -inf, not the NaN its residuals would give
+    auto pk = [&](int i) { return (unsigned)t[i] | ((unsigned)t[i + 1] << 16); };
+    L.coefA[sb][0][row] = qu4{pk(0), pk(2), pk(4), pk(6)};
+    L.coefA[sb][1][row] = qu4{pk(8), pk(10), pk(12), pk(14)};
+    L.coefB[sb][row] = pk(16);
     L.uni[slot] = u;
 }
 
@@ -91,68 +122,45 @@ __device__ __forceinline__ void pixel_of_lane(int wave, int lane, int& lx, int& 
     ly = ((wave >> 1) << 3) + (lane >> 3);
 }
 
-struct Basis { float bx[3], by[3]; };
+struct Basis { qu4 x1, y1; unsigned x2, y2; };      // B operands of the X and Y column blocks: first instruction, second
+
+// slot -> which basis function it multiplies (see Staged): three slots per coefficient
+__device__ __forceinline__ unsigned basis_slot_bits(int slot, float u, float v) {
+    if (slot >= 18) return 0u;
+    return __builtin_bit_cast(unsigned, basis_of(slot / 3, u, v)) >> 16;          // exact in bf16
+}
 
 __device__ __forceinline__ Basis make_basis(int wave, int lane) {
     Basis b;
     const int h = lane >> 5;
     int lx, ly;
-    pixel_of_lane(wave, lane & 31, lx, ly);
-    float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
 #pragma unroll
-    for (int q = 0; q < 3; q++) b.bx[q] = basis_of(2 * q + h, u, v);
-    pixel_of_lane(wave, 32 + (lane & 31), lx, ly);
-    u = (float)lx - 7.5f; v = (float)ly - 7.5f;
+    for (int blk = 0; blk < 2; blk++) {
+        pixel_of_lane(wave, 32 * blk + (lane & 31), lx, ly);
+        const float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
+        qu4 w;
 #pragma unroll
-    for (int q = 0; q < 3; q++) b.by[q] = basis_of(2 * q + h, u, v);
+        for (int e = 0; e < 4; e++) w[e] = basis_slot_bits(8 * h + 2 * e, u, v) | (basis_slot_bits(8 * h + 2 * e + 1, u, v) << 16);
+        const unsigned w2 = h == 0 ? (basis_slot_bits(16, u, v) | (basis_slot_bits(17, u, v) << 16)) : 0u;
+        if (blk == 0) { b.x1 = w; b.x2 = w2; } else { b.y1 = w; b.y2 = w2; }
+    }
     return b;
 }
 
 // log2 alpha (opacity folded in, NOT yet clamped) of this lane's pixel against the 32 splats of sub-batch
 // `sb`: s[i] for row i in depth order.
-struct Acc2 { f16v X, Y; };
-
-// the six MFMAs of a sub-batch, issued; their results are not touched here, so the caller can put independent work behind them
-__device__ __forceinline__ Acc2 issue_sub_batch(const Staged& L, int sb, int lane, const Basis& b) {
-    const int h = lane >> 5, row = lane & 31;
-    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
-    Acc2 r;
-    r.X = f16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    r.Y = r.X;
-    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], r.X, 0, 0, 0);
-    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], r.Y, 0, 0, 0);
-    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], r.X, 0, 0, 0);
-    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], r.Y, 0, 0, 0);
-    r.X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], r.X, 0, 0, 0);
-    r.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], r.Y, 0, 0, 0);
-    return r;
-}
-
-// the 16 swaps that give every lane its own pixel's 32 rows (see eval_sub_batch)
-__device__ __forceinline__ void finish_sub_batch(const Acc2& acc, float s[SUB]) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float xv = acc.X[r], yv = acc.Y[r];
-        auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xv), __builtin_bit_cast(unsigned, yv),
-                                                   false, false);
-        const unsigned x_new = sw[0], y_new = sw[1];
-        const int row0 = (r & 3) + 8 * (r >> 2);
-        s[row0] = __builtin_bit_cast(float, x_new);
-        s[row0 + 4] = __builtin_bit_cast(float, y_new);
-    }
-}
-
 __device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane, const Basis& b, float s[SUB]) {
     const int h = lane >> 5, row = lane & 31;
-    const float a0 = L.coef[sb][h][row], a1 = L.coef[sb][2 + h][row], a2 = L.coef[sb][4 + h][row];
+    const qu4 a1 = L.coefA[sb][h][row];
+    const unsigned a2w = L.coefB[sb][row];
+    const qu4 a2 = {h == 0 ? a2w : 0u, 0u, 0u, 0u};
+    const qu4 bx2 = {b.x2, 0u, 0u, 0u}, by2 = {b.y2, 0u, 0u, 0u};
     f16v X = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f16v Y = X;
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.bx[0], X, 0, 0, 0);
-    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.by[0], Y, 0, 0, 0);
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.bx[1], X, 0, 0, 0);
-    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.by[1], Y, 0, 0, 0);
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.bx[2], X, 0, 0, 0);
-    Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.by[2], Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qbf8, a1), __builtin_bit_cast(qbf8, b.x1), X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qbf8, a1), __builtin_bit_cast(qbf8, b.y1), Y, 0, 0, 0);
+    X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qbf8, a2), __builtin_bit_cast(qbf8, bx2), X, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qbf8, a2), __builtin_bit_cast(qbf8, by2), Y, 0, 0, 0);
     // register r of a 32x32 accumulator = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  swap(X[r], Y[r]) hands X's
     // upper-half rows to the lower lanes and Y's lower-half rows to the upper lanes: afterwards, on every lane,
     // X[r] = row (r & 3) + 8 (r >> 2) and Y[r] = that + 4 of the lane's OWN pixel.

@@ -33,7 +33,7 @@
 
 namespace mfma_raster {
 
-template <bool HAS_BG, bool PIPE>
+template <bool HAS_BG>
 __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
@@ -67,19 +67,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
         }
         __syncthreads();
         const int bsz = min(BLOCK, end - bs);
-        Acc2 acc_next;
-        if (PIPE) acc_next = issue_sub_batch(L, 0, lane, basis);
         for (int sb = 0; sb * SUB < bsz; sb++) {
             if (live == 0ull) break;
             float s[SUB];
-            if (PIPE) {
-                // the MFMAs of sub-batch sb + 1 go out before sub-batch sb is composited: their 3 x 64-cycle dependent
-                // chain then runs behind ~1 000 cycles of vector work instead of in front of it
-                finish_sub_batch(acc_next, s);
-                if ((sb + 1) * SUB < bsz) acc_next = issue_sub_batch(L, sb + 1, lane, basis);
-            } else {
-                eval_sub_batch(L, sb, lane, basis, s);
-            }
+            eval_sub_batch(L, sb, lane, basis, s);
             const lds_f4_ptr uni = opaque_lds_base(&L.uni[sb * SUB]);
             Rgb col_next = lds_rgb(uni, 0);
 #pragma unroll
@@ -326,11 +317,11 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, float* render, float* alphas, int32_t* last_ids, int prefetch, hipStream_t st) {
     using namespace mfma_raster;
-#define LAUNCH_FWD(BG, PF)                                                                                                \
-    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG, PF>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+#define LAUNCH_FWD(BG)                                                                                                    \
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,     \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids)
-    if (backgrounds) { if (prefetch) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); }
-    else { if (prefetch) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false); }
+    (void)prefetch;      // (a variant with the next sub-batch's MFMAs issued early was measured slower and is gone)
+    if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
 #undef LAUNCH_FWD
     MI_LAUNCH_CHECK();
     return 0;

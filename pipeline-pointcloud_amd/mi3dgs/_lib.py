@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi3dgs.so")
+# MI3DGS_LIB: another build of the same ABI, for same-box A/B measurements of two versions of a kernel
+LIB_PATH = os.environ.get("MI3DGS_LIB") or os.path.join(_HERE, "libmi3dgs.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 
 _lib: Optional[C.CDLL] = None
