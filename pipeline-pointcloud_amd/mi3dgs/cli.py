@@ -115,7 +115,7 @@ def splatfacto_config(model: str, max_steps: int, scale_reg: bool, n_train: int,
         prune_opa=0.005 if big else 0.1, grow_grad2d=0.0005 if big else 0.0008, grow_scale3d=0.01, prune_scale3d=0.5,
         refine_start_iter=500, refine_stop_iter=15000, reset_every=3000, refine_every=100,
         pause_refine_after_reset=n_train + 100, absgrad=True, use_scale_regularization=scale_reg,
-        random_background=True, capacity=capacity,
+        random_background=True, capacity=capacity, auto_isect_capacity=True,
         num_downscales=2, resolution_schedule=3000)          # splatfacto: 1/4 -> 1/2 -> full, every 3000 steps
 
 
@@ -123,7 +123,7 @@ def simple_trainer_config(a: Dict, capacity: int):
     from .trainer import TrainConfig
     cfg = TrainConfig(max_steps=a["max_steps"], capacity=capacity, antialiased=a["antialiased"],
                       random_background=a["random_bkgd"], absgrad=a["absgrad"],
-                      grow_grad2d=0.0008 if a["absgrad"] else 0.0002, scene_scale=1.1)
+                      grow_grad2d=0.0008 if a["absgrad"] else 0.0002, scene_scale=1.1, auto_isect_capacity=True)
     f = a["steps_scaler"]
     if f != 1.0:        # gsplat Config.adjust_steps
         import dataclasses
@@ -214,6 +214,8 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
                 say(f"  {k:24s} {v[1] / (prof_b - prof_a):7.3f} ms/step  {v[0] / (prof_b - prof_a):5.1f} launches  {1e3 * v[1] / max(v[0], 1):8.1f} us each")
         want = (step % log_every == 0) or step == cfg.max_steps - 1
         loss = tr.step(view_of(step * world + rank), want_loss=want)
+        if want:
+            tr.check_async_errors()        # the host has just waited for the loss: device error word, capacity of the tile lists
         if want and rank == 0:
             now = time.time()
             rate = (step - s_last + 1) / max(now - t_last, 1e-9)

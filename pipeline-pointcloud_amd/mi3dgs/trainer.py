@@ -71,6 +71,10 @@ class TrainConfig:
     # count back every step and allocate exactly; an int = no host sync in the step)
     capacity: Optional[int] = None
     max_isect: Optional[int] = None
+    # max_isect is None: size the intersection buffers from measured counts (every training view once at start and at a
+    # resolution change, a device-side running peak afterwards) and grow them on demand, so that a training step never reads
+    # the count back: no host sync per step, and the fused chained binning instead of the count / emit pair
+    auto_isect_capacity: bool = False
     # exact ellipse-tile culling at binning time (identical renders/gradients, fewer intersections)
     tight_tiles: bool = True
     # capacity mode only: count and emit fused in one chained pass (mi3dgs_bin_tiles)
@@ -152,6 +156,9 @@ class Trainer:
                         if images is not None and images.dtype == torch.uint8 else None)
         self.W, self.H = int(width), int(height)
         self.W0, self.H0, self.Ks0, self._cur_d = self.W, self.H, self.Ks, 1
+        self._auto_cap: Optional[int] = None       # auto_isect_capacity: current capacity, None = measure first
+        self._isect_peak = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.isect_overflows = 0
         self.step_count = 0
         cap = self.model.capacity
         self.radii = torch.empty(1, cap, 2, dtype=torch.int32, device=dev)
@@ -203,6 +210,7 @@ class Trainer:
         if d == self._cur_d:
             return
         self._cur_d = d
+        self._auto_cap = None                 # intersection counts scale with the tile grid: measure again
         self.W, self.H = max(1, self.W0 // d), max(1, self.H0 // d)
         self.Ks = self.Ks0.clone()
         self.Ks[:, :2, :] /= float(d)
@@ -236,16 +244,21 @@ class Trainer:
         lr_means = c.lr_means * c.scene_scale * (c.lr_means_final_ratio ** t)
         return (lr_means, c.lr_quats, c.lr_scales, c.lr_opacities, c.lr_sh0, c.lr_shN)
 
-    def _forward(self, viewmat, K, sh_degree, background=None):
+    def _forward(self, viewmat, K, sh_degree, background=None, exact_isect=False):
         m, n = self.model, self._n()
         radii, splats = self.radii[:, :n], self.splats[:, :n]
+        cap = self.cfg.max_isect
+        if cap is None and self.cfg.auto_isect_capacity and not exact_isect:
+            cap = self._auto_cap
         # with a capacity the binning is one fused call that takes its sort keys straight from the projection
-        keys = self.depth_keys[:, :n] if (self.cfg.fused_binning and self.cfg.max_isect is not None) else None
+        keys = self.depth_keys[:, :n] if (self.cfg.fused_binning and cap is not None) else None
         ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
-        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=self.cfg.max_isect, tight=self.cfg.tight_tiles,
+        binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=cap, tight=self.cfg.tight_tiles,
                                 fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True)
+        if self.cfg.auto_isect_capacity and self.cfg.max_isect is None:
+            torch.maximum(self._isect_peak, binning["n_isect"], out=self._isect_peak)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids
@@ -255,7 +268,8 @@ class Trainer:
         """Render one view at full resolution: [1,H,W,3], [1,H,W,1].  (Outputs alias internal buffers.)"""
         self.set_resolution(1)
         sd = self.cfg.sh_degree if sh_degree is None else sh_degree
-        _, _, _, render, alphas, _ = self._forward(viewmat.view(1, 4, 4), K.view(1, 3, 3), sd, background)
+        # (an arbitrary camera: the auto-sized capacity was measured on the training views only, so count exactly here)
+        _, _, _, render, alphas, _ = self._forward(viewmat.view(1, 4, 4), K.view(1, 3, 3), sd, background, exact_isect=True)
         return render, alphas
 
     # -- one training iteration ------------------------------------------------------
@@ -264,6 +278,8 @@ class Trainer:
         c, m = self.cfg, self.model
         n = self._n()
         self.set_resolution(self.downscale_now())
+        if c.auto_isect_capacity and c.max_isect is None and self._auto_cap is None:
+            self.calibrate_isect_capacity()
         viewmat = self.viewmats[view_index: view_index + 1]
         K = self.Ks[view_index: view_index + 1]
         gt = self._target(view_index)
@@ -453,6 +469,35 @@ class Trainer:
     def _can_fuse_adam(self) -> bool:
         return True
 
+    # -- intersection capacity (auto_isect_capacity) -------------------------------------
+    def calibrate_isect_capacity(self, margin: float = 2.0) -> int:
+        """Bin every training view once at the current resolution (count read back: V host syncs, once) and size the
+        buffers at `margin` x the worst view."""
+        self._auto_cap = None
+        sd = self.sh_degree_now()
+        worst = 0
+        for i in range(self.viewmats.shape[0]):
+            _, _, binning, _, _, _ = self._forward(self.viewmats[i: i + 1], self.Ks[i: i + 1], sd)
+            worst = max(worst, int(binning["n_isect"].item()))
+        self._auto_cap = int(margin * worst) + (1 << 18)
+        self._isect_peak.zero_()
+        return self._auto_cap
+
+    def _auto_cap_check(self, bad_bits: int = 0, scale: float = 1.0) -> None:
+        """Where the host waits anyway (refine, periodic checks): grow the capacity when the running peak comes near it, or
+        when a view overflowed it (its lists were truncated for the steps since the last check, which is logged)."""
+        if not (self.cfg.auto_isect_capacity and self.cfg.max_isect is None) or self._auto_cap is None:
+            return
+        peak = int(self._isect_peak.item())
+        self._isect_peak.zero_()
+        cap = self._auto_cap
+        if (bad_bits & 4) or peak >= cap:
+            self.isect_overflows += 1
+            cap = 2 * max(cap, peak)
+        elif peak > 0.6 * cap:
+            cap = int(2.0 * peak) + (1 << 18)
+        self._auto_cap = max(cap, int(cap * scale))
+
     # -- DefaultStrategy.step_post_backward --------------------------------------------
     def _strategy_post_step(self):
         c, step = self.cfg, self.step_count
@@ -472,6 +517,9 @@ class Trainer:
         offsets downstream) or a view produced more tile intersections than `max_isect` (bit 4: lists
         truncated).  Call it where the host waits anyway: refine, end of training, end of a benchmark."""
         bad = self._async_error_bits()
+        if self.cfg.auto_isect_capacity and self.cfg.max_isect is None:
+            self._auto_cap_check(bad)
+            bad &= ~4
         if bad & 3:
             raise ops._lib.Mi3dgsError(f"a chained kernel gave up waiting (bits {bad:#x}); results since the last check are invalid")
         if bad & 4:
@@ -507,6 +555,8 @@ class Trainer:
         info = dict(n_before=n, n_after=new_n, n_dup=hist[1], n_split=hist[2], n_prune=hist[4] + hist[5] + hist[6] + hist[7])
         m.cur = 1 - m.cur
         m.n = new_n
+        if self._auto_cap is not None and new_n > n:
+            self._auto_cap = int(self._auto_cap * (new_n / max(n, 1)))      # more Gaussians, more intersections: ahead of the peak check
         for v in self.stats.values():
             v.zero_()
         self.last_refine = info

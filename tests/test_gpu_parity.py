@@ -388,6 +388,43 @@ def test_training_recovers_target(dev):
     assert last < 0.5 * first, (first, last)
 
 
+def test_auto_isect_capacity_follows_the_exact_path_and_grows_on_overflow(dev):
+    """TrainConfig.auto_isect_capacity (what the ns-train / simple_trainer shims run with): tile-list buffers sized from
+    measured counts so that no step reads the count back.  Same training as the exact (count read back every step) path up
+    to float-atomic order; a capacity made too small on purpose is reported, not fatal, and grows."""
+    import dataclasses
+    from mi3dgs import trainer
+    sc = small_scene(n=1500, seed=12, big=True, width=96, height=64, n_views=4, fx=90.0)
+    g = sc.to(dev)
+    tr0 = trainer.Trainer(g.params, g.viewmats, g.Ks, torch.zeros(4, 64, 96, 3, device=dev), 96, 64,
+                          trainer.TrainConfig(densify=False))
+    imgs = torch.cat([tr0.render(g.viewmats[i], g.Ks[i])[0].clone() for i in range(4)]) * 0.8 + 0.1
+    cfg = trainer.TrainConfig(max_steps=200, sh_degree_interval=1, refine_start_iter=5, refine_every=10, capacity=6000)
+    P0 = {k: v.clone() for k, v in g.params.items()}
+    tr_x = trainer.Trainer({k: v.clone() for k, v in P0.items()}, g.viewmats, g.Ks, imgs, 96, 64, cfg)
+    tr_a = trainer.Trainer({k: v.clone() for k, v in P0.items()}, g.viewmats, g.Ks, imgs, 96, 64,
+                           dataclasses.replace(cfg, auto_isect_capacity=True))
+    for i in range(40):
+        tr_x.step(i % 4)
+        tr_a.step(i % 4)
+    tr_a.check_async_errors()
+    assert tr_a._auto_cap is not None and tr_a.isect_overflows == 0
+    assert tr_a.last_binning["max_isect"] == tr_a.last_binning["flatten_ids"].numel() > 0      # the capacity path ran
+    assert tr_a.model.n == tr_x.model.n > 1500                                                  # same refine decisions
+    for grp in ("means", "scales", "opacities", "sh0"):
+        a, x = tr_a.model.p(grp)[: tr_a.model.n], tr_x.model.p(grp)[: tr_x.model.n]
+        assert rel_err(a, x) < 1e-3, grp
+    # far too small: the emit pass clamps, the sticky word says so, the trainer grows instead of raising
+    tr_a._auto_cap = 256
+    tr_a.step(0)
+    tr_a.check_async_errors()
+    assert tr_a.isect_overflows == 1 and tr_a._auto_cap >= 512
+    tr_a.calibrate_isect_capacity()
+    tr_a.step(1)
+    tr_a.check_async_errors()
+    assert tr_a.isect_overflows == 1
+
+
 # ------------------------------------------------------------- exact ("tight") tile culling
 @pytest.mark.parametrize("seed,big", [(41, True), (42, False), (43, True)])
 def test_tight_binning_is_conservative_and_renders_bit_identical(dev, seed, big):
