@@ -157,7 +157,8 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     Cn, N = radii.shape[0], radii.shape[1]
     dev = radii.device
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
-    n_isect = torch.zeros(1, dtype=torch.int32, device=dev)
+    # (both entry points clear the count themselves; only a call that returns early on an empty scene relies on this fill)
+    n_isect = torch.zeros(1, dtype=torch.int32, device=dev) if (N == 0 or max_isect == 0) else torch.empty(1, dtype=torch.int32, device=dev)
     tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev) if want_tiles_per_gauss else None
     # the phase-1 layout depends on max_isect only for its tail, so count with cap 0 when unknown
     cap_known = max_isect is not None
