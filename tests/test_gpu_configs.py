@@ -250,6 +250,43 @@ def test_adam_two_million_matches_torch_optim(dev):
         assert bool(torch.isfinite(t).all())
 
 
+@pytest.mark.parametrize("kind,cam,absgrad,with_bg", [("lego", 3, True, True), ("garden", 1, False, False), ("garden", 2, True, True)])
+def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad, with_bg):
+    """The product backward contracts its per-splat pixel sums on the matrix pipe, carrying every term as two bf16 values
+    (csrc/rasterize_bwd_mm.hip); the reduce-scatter kernel of the first half of round 2 sums the same terms in float32 on
+    the vector pipe (MI3DGS_RASTER_MODE=3).  Same forward, same lists: the gradient records must agree to the transport's
+    2^-16 per term -- checked on the full S1 / S2 scenes, with and without background and |d/dxy| sums."""
+    ops = _ops()
+    sc = _scene(kind)
+    W, H = sc.width, sc.height
+    g, vm, K, radii, splats, keys = _project(sc, dev, cam, want_keys=True)
+    b = ops.bin_tiles(radii, splats, W, H, 16, tight=True)
+    bg = torch.tensor([[0.3, 0.6, 0.1]], device=dev) if with_bg else None
+    r, a, l = ops.rasterize_fwd(splats, b, W, H, 16, bg, {})
+    gen = torch.Generator().manual_seed(9)
+    vr = (torch.rand(1, H, W, 3, generator=gen) - 0.5).to(dev)
+    va = (torch.rand(1, H, W, 1, generator=gen) - 0.5).to(dev)
+    lib = ops._lib.lib()
+    outs = []
+    try:
+        for mode in (1, 3):
+            lib.mi3dgs_debug_set_raster_mode(mode)
+            outs.append(ops.rasterize_bwd(splats, b, W, H, a, l, vr, va, 16, bg, absgrad).clone())
+    finally:
+        lib.mi3dgs_debug_set_raster_mode(1)
+    mm, rs = outs
+    assert bool(torch.isfinite(mm).all()) and float(rs.abs().sum()) > 0
+    ncol = 11 if absgrad else 9
+    for c in range(ncol):
+        x, y = mm[0, :, c].double(), rs[0, :, c].double()
+        assert float((x - y).norm() / y.norm().clamp(min=1e-30)) < 2e-5, (c, float((x - y).norm() / y.norm()))
+    # per record: the difference stays at the level of the transport (and of float atomics landing in another order)
+    d = (mm[0, :, :ncol] - rs[0, :, :ncol]).abs().double()
+    scale = rs[0, :, :ncol].abs().double().amax(dim=0, keepdim=True).clamp(min=1e-30)
+    assert float((d / scale).max()) < 1e-4
+    assert ops._lib.async_errors() == 0
+
+
 def test_s2_training_step_properties_and_fused_adam(dev):
     """One whole training step of the bench configuration (2 M Gaussians, 1080p, capacity mode, fused
     binning, fused backward + Adam) against the unfused sequence on the same inputs; then the properties."""
