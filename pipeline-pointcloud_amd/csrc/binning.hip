@@ -18,6 +18,7 @@
 // from device memory, so the stage runs without a host sync when the caller sizes the
 // intersection buffers by capacity.
 #include "common.h"
+#include <stdlib.h>
 #include <stdio.h>
 
 namespace {
@@ -202,9 +203,16 @@ constexpr int RS_WAVE_TILE = RS_TILE / 4;        // 1024 consecutive keys per wa
 // the onesweep passes (small, latency-bound sorts) use LARGER tiles than the classic ones: fewer links in
 // the look-back chain.  Measured on the 2 M-key depth sort, us per pass: 8 items/thread 42.7, 16: 32.3,
 // 32: 30.0, 48: 45.1 (spills)
-constexpr int OS_ITEMS = 32;
-constexpr int OS_TILE = RS_THREADS * OS_ITEMS;
-constexpr int OS_WAVE_TILE = OS_TILE / 4;
+// Small sorts (the early, low-resolution phase of real training: 10^4 - 10^5 keys) are a handful of tiles whichever size,
+// and a thread then walks its 32 rounds for nothing: 8 items per thread below 128 K keys (S0 cube, 10 k Gaussians: depth-sort
+// pass 18.6 -> 12 us).
+constexpr int OS_ITEMS_BIG = 32, OS_ITEMS_SMALL = 8;
+inline uint32_t os_small_keys() {
+    static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_SMALL_KEYS"); return e ? (uint32_t)atol(e) : (128u << 10); }();
+    return v;
+}
+inline int os_items_for(uint32_t cap) { return cap <= os_small_keys() ? OS_ITEMS_SMALL : OS_ITEMS_BIG; }
+inline uint32_t os_tiles_for(uint32_t cap) { return (uint32_t)mi_div_up(cap, (long long)RS_THREADS * os_items_for(cap)); }
 
 __device__ __forceinline__ uint32_t live_count(const uint32_t* n_ptr, uint32_t cap) {
     if (!n_ptr) return cap;
@@ -359,13 +367,14 @@ constexpr unsigned OS_SPIN_LIMIT = CHAIN_SPIN_LIMIT;
 // DROP: keys equal to 0xFFFFFFFF (the depth sort's "culled" sentinel) are not counted; the number of the others
 // goes to *n_live_out, and pass 0 (os_pass_kernel<DROP>) leaves them behind, so the later passes -- and
 // everything downstream of the sort -- work on the visible splats only.
-template <bool DROP>
+template <bool DROP, int OS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap, int passes,
                                                              int per, int nbits, uint32_t* __restrict__ ghist /*[passes][256]*/,
                                                              uint32_t* __restrict__ n_live_out) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     uint32_t n = live_count(n_ptr, cap);
+    constexpr int OS_TILE = RS_THREADS * OS_ITEMS;
     uint32_t base = blockIdx.x * OS_TILE;
     if (base >= n) return;
 #pragma unroll
@@ -402,12 +411,13 @@ __device__ __forceinline__ unsigned long long os_pack(uint32_t epoch, uint32_t f
     return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned long long)value;
 }
 
-template <bool DROP>
+template <bool DROP, int OS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ ghist_pass /*[256]*/, unsigned long long* status /*[tiles][256]*/,
     uint32_t* tile_counter, uint32_t epoch, uint32_t* err) {
+    constexpr int OS_TILE = RS_THREADS * OS_ITEMS, OS_WAVE_TILE = OS_TILE / 4;
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t delta[256];
     __shared__ uint32_t skey[OS_TILE], sval[OS_TILE];
@@ -528,13 +538,13 @@ size_t rs_tmp_u32(uint32_t cap) {
     uint32_t B = mi_div_up(cap, RS_TILE);
     size_t hist = (size_t)256 * B;
     size_t classic = hist + scan_tmp_u32(hist);
-    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + 2 * (size_t)256 * mi_div_up(cap, OS_TILE) + 16;
+    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + 2 * (size_t)256 * os_tiles_for(cap) + 16;
     return classic > onesweep ? classic : onesweep;
 }
 
 size_t rs_zero_u32(uint32_t cap, int nbits) {
     const int passes = (nbits + 7) / 8;
-    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * mi_div_up(cap, OS_TILE);
+    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * os_tiles_for(cap);
     size_t classic = (size_t)passes * align_u32(scan_tmp_u32((size_t)256 * mi_div_up(cap, RS_TILE)));
     return align_u32(onesweep > classic ? onesweep : classic);
 }
@@ -566,7 +576,8 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     int shift = 0;
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
     if (g_sort_mode == 1 || (g_sort_mode == 2 && cap <= OS_MAX_KEYS)) {
-        const uint32_t B = mi_div_up(cap, OS_TILE);          // (shadows the classic tile count)
+        const uint32_t B = os_tiles_for(cap);          // (shadows the classic tile count)
+        const bool small = os_items_for(cap) == OS_ITEMS_SMALL;
         // layout: ghist[4][256] | counters[8] err[1] pad[7] | status[B][256] u64
         uint32_t* ctl = zeroed ? zeroed : tmp;
         uint32_t* ghist = ctl;
@@ -579,19 +590,25 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         if (n_live_out) {
             MI_REQUIRE(!n_ptr, "sort: sentinel dropping needs a host-known input size");
             if (!zeroed) MI_HIP(hipMemsetAsync(n_live_out, 0, sizeof(uint32_t), st));
-            MI_LAUNCH(htag, os_hist_kernel<true>, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            if (small) MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            else MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         } else {
-            MI_LAUNCH(htag, os_hist_kernel<false>, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            if (small) MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            else MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         }
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
             if (n_live_out && p == 0)
-                MI_LAUNCH(ctag, os_pass_kernel<true>, dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
+                { if (small) MI_LAUNCH(ctag, (os_pass_kernel<true, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
                           ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
+                  else MI_LAUNCH(ctag, (os_pass_kernel<true, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
+                          ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err); }
             else
-                MI_LAUNCH(ctag, os_pass_kernel<false>, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
+                { if (small) MI_LAUNCH(ctag, (os_pass_kernel<false, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
                           n_live_out ? n_live_out : n_ptr, cap, shift, mask, ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
+                  else MI_LAUNCH(ctag, (os_pass_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
+                          n_live_out ? n_live_out : n_ptr, cap, shift, mask, ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err); }
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
