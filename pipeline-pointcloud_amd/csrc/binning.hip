@@ -204,11 +204,11 @@ constexpr int RS_WAVE_TILE = RS_TILE / 4;        // 1024 consecutive keys per wa
 // the look-back chain.  Measured on the 2 M-key depth sort, us per pass: 8 items/thread 42.7, 16: 32.3,
 // 32: 30.0, 48: 45.1 (spills)
 // Small sorts (the early, low-resolution phase of real training: 10^4 - 10^5 keys) are a handful of tiles whichever size,
-// and a thread then walks its 32 rounds for nothing: 8 items per thread below 128 K keys (S0 cube, 10 k Gaussians: depth-sort
+// and a thread then walks its 32 rounds for nothing: 8 items per thread up to 512 K keys (measured: S1, 300 k keys, 23.2 -> 17.3 us per pass; S2, 2 M keys, 29 -> 40 us, so not there; S0 cube, 10 k Gaussians: depth-sort
 // pass 18.6 -> 12 us).
 constexpr int OS_ITEMS_BIG = 32, OS_ITEMS_SMALL = 8;
 inline uint32_t os_small_keys() {
-    static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_SMALL_KEYS"); return e ? (uint32_t)atol(e) : (128u << 10); }();
+    static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_SMALL_KEYS"); return e ? (uint32_t)atol(e) : (512u << 10); }();
     return v;
 }
 inline int os_items_for(uint32_t cap) { return cap <= os_small_keys() ? OS_ITEMS_SMALL : OS_ITEMS_BIG; }
