@@ -181,7 +181,11 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
                          const int32_t* flatten_ids, const int32_t* n_isect_dev,
                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids,
                          void* stream);
-/* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it. */
+/* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it.
+ * Numerics: log2 alpha of a (pixel, splat) pair is evaluated by the forward's own instruction sequence (three-term bf16
+ * coefficients against an exact bf16 basis, f32 accumulation), so forward and backward take the same alpha >= 1/255 decision;
+ * the per-splat sums over a tile's pixels are carried to their f32 accumulators as two bf16 terms per value (relative error
+ * <= 2^-16 per term, unbiased).  mi3dgs_debug_set_raster_mode(3) selects the all-f32 reduction of the same sums. */
 int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width,
                          int tile_height, const float* splats, const int32_t* isect_offsets,
                          const int32_t* flatten_ids, const int32_t* n_isect_dev,

@@ -175,6 +175,7 @@ class Trainer:
         self.offs_buf = torch.empty(cap, dtype=torch.int32, device=dev)
         self.total_buf = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
+        self.dev_gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed + 1)   # per-step draws stay on the device
         self.last: Dict = {}
         self.last_refine: Dict = {}
         self.refine_totals: Dict = {}
@@ -286,7 +287,7 @@ class Trainer:
         sd = self.sh_degree_now()
         bg = None
         if c.random_background:
-            bg = torch.rand(1, 3, generator=self.gen).to(self.device)
+            bg = torch.rand(1, 3, generator=self.dev_gen, device=self.device)      # (was drawn on the host and copied every step)
         radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg)
         sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch)
         ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
