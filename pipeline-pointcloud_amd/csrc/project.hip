@@ -354,12 +354,20 @@ struct GeoGrad {
     float vopa;
 };
 
+// rec_conic: the conic the FORWARD stored in the splat record (what the rasteriser used, and what v_conic is the gradient
+// of).  Recomputing it here is not just redundant: det = a c - b^2 cancels catastrophically for a needle-thin Gaussian that
+// projects thousands of pixels wide (a ~ c ~ 1e7: the difference is all rounding), the forward's instruction sequence gave a
+// small positive det and this kernel's, contracted differently, gave 0 -> 1 / det = inf -> 0 * inf = NaN in every
+// geometric gradient even with an all-zero gradient record.  Found in the MCMC synthetic run (one Gaussian in ~5 000 steps; a
+// NaN Gaussian is never visible again but keeps its opacity, is picked as a relocation source and spreads:
+// tools/nan_probe.py reproduces the single call).
 __device__ __forceinline__ void geo_bwd_one_camera(const Cam& cam, const float mean[3], const float Sw[9], int W, int H,
                                                    float eps2d, int flags, float opa_act, float v_m2x, float v_m2y,
                                                    float v_cA, float v_cB, float v_cC, float v_op, float v_depth,
-                                                   GeoGrad& G) {
+                                                   float recA, float recB, float recC, GeoGrad& G) {
     Proj P;
     project_core(cam, mean, Sw, W, H, eps2d, P);
+    P.conA = recA; P.conB = recB; P.conC = recC;
     float vcov_a = 0.f, vcov_b = 0.f, vcov_c = 0.f;   // symmetric 2x2 grad: [[a, b],[b, c]]
     if (flags & MI_FLAG_ANTIALIASED) {
         G.vopa += v_op * P.comp;
@@ -418,6 +426,17 @@ __device__ __forceinline__ void geo_bwd_one_camera(const Cam& cam, const float m
     mat3_mul(tmp, cam.R, acc);
 #pragma unroll
     for (int i = 0; i < 9; i++) G.vSw[i] += acc[i];
+}
+
+// last line of defence for the optimiser: a non-finite geometric gradient (overflow in a degenerate projection) is dropped
+// for that Gaussian and step instead of being written into its parameters and moments for good
+__device__ __forceinline__ void drop_nonfinite_geo(float (&vmean)[3], float (&vq)[4], float (&vs)[3]) {
+    const float t = vmean[0] + vmean[1] + vmean[2] + vq[0] + vq[1] + vq[2] + vq[3] + vs[0] + vs[1] + vs[2];
+    if (!__builtin_isfinite(t)) {
+        vmean[0] = vmean[1] = vmean[2] = 0.f;
+        vq[0] = vq[1] = vq[2] = vq[3] = 0.f;
+        vs[0] = vs[1] = vs[2] = 0.f;
+    }
 }
 
 // Sigma = M M^T, M = R(q) diag(s)  ->  v_quat (through the normalisation), v_scale
@@ -584,10 +603,10 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             rmax = fmaxf((float)rad.x, (float)rad.y) / (float)max(W, H);
         }
         Cam cam = load_cam(viewmats, Ks, 0);
-        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, G);
-        // ---- colour path
         const float4* sr = reinterpret_cast<const float4*>(splats + (long long)n * SPLAT_STRIDE);
-        float4 s1 = sr[1], s2 = sr[2];
+        const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2];
+        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, s0.z, s0.w, s1.x, G);
+        // ---- colour path
         if (s1.z <= 0.f) v_rgb[0] = 0.f;        // clamp(+0.5, min 0) mask
         if (s1.w <= 0.f) v_rgb[1] = 0.f;
         if (s2.x <= 0.f) v_rgb[2] = 0.f;
@@ -629,6 +648,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             covar_bwd(Rq, s, q, inv_norm, G.vSw, vq, vs);
             if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
             if (flags & MI_FLAG_LOGIT_OPAC) G.vopa *= opa_act * (1.f - opa_act);
+            drop_nonfinite_geo(G.vmean, vq, vs);
         }
         if (stat_grad2d && vis) {
             stat_grad2d[n] += g2d;
@@ -809,10 +829,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
             rmax = fmaxf(rmax, fmaxf((float)rad.x, (float)rad.y) / (float)max(W, H));
         }
         Cam cam = load_cam(viewmats, Ks, c);
-        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, G);
+        const float4* sr = reinterpret_cast<const float4*>(splats + idx * SPLAT_STRIDE);
+        const float4 s0 = sr[0], s1 = sr[1];
+        geo_bwd_one_camera(cam, mean, Sw, W, H, eps2d, flags, opa_act, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g2.w, s0.z, s0.w, s1.x, G);
         if (color_mode == 0) {
-            const float4* sr = reinterpret_cast<const float4*>(splats + idx * SPLAT_STRIDE);
-            float4 s1 = sr[1], s2 = sr[2];
+            float4 s2 = sr[2];
             if (s1.z <= 0.f) v_rgb[0] = 0.f;        // clamp(+0.5, min 0) mask
             if (s1.w <= 0.f) v_rgb[1] = 0.f;
             if (s2.x <= 0.f) v_rgb[2] = 0.f;
@@ -849,9 +870,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     }
     float vq[4], vs[3];
     covar_bwd(Rq, s, q, inv_norm, G.vSw, vq, vs);
+    if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
+    drop_nonfinite_geo(G.vmean, vq, vs);
 #pragma unroll
     for (int i = 0; i < 4; i++) v_quats[4 * n + i] = vq[i];
-    if (flags & MI_FLAG_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
     v_scales[3 * n] = vs[0]; v_scales[3 * n + 1] = vs[1]; v_scales[3 * n + 2] = vs[2];
     v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
     if (v_opacities) {

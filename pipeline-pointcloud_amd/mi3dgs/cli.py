@@ -238,6 +238,15 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
             ps.append(psnr(r[0].clamp(0, 1), ev[j]))
         stats["eval_psnr"] = sum(ps) / len(ps)
         say(f"eval: psnr={stats['eval_psnr']:.2f} dB over {len(ps)} held-out images")
+        if os.environ.get("MI3DGS_EVAL_DETAIL"):
+            say("eval per view: " + " ".join(f"{p:.1f}" for p in ps))
+            trn = ds.load_images(ds.train_idx[:8], dev)
+            pt = [psnr(tr.render(ds.viewmats[i].to(dev), ds.Ks[i].to(dev))[0][0].clamp(0, 1), trn[j]) for j, i in enumerate(ds.train_idx[:8])]
+            say("train per view: " + " ".join(f"{p:.1f}" for p in pt))
+            op = torch.sigmoid(tr.model.p("opacities")[: tr.model.n].flatten())
+            sc = tr.model.p("scales")[: tr.model.n].exp().amax(-1)
+            say(f"opacity quantiles {[round(float(q), 4) for q in torch.quantile(op[:1_000_000], torch.tensor([0.1, 0.5, 0.9, 0.99], device=op.device))]} "
+                f"max scale quantiles {[round(float(q), 4) for q in torch.quantile(sc[:1_000_000], torch.tensor([0.5, 0.9, 0.99, 1.0], device=op.device))]}")
     if rank == 0:
         say(f"trained in {train_s:.1f}s = {stats['iters_per_sec']:.1f} it/s, {tr.model.n} Gaussians")
     return tr, ds, stats

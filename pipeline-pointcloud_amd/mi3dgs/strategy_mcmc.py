@@ -22,6 +22,7 @@ from . import ops
 from .trainer import GROUPS, TrainConfig, Trainer
 
 N_MAX = 51
+_NAN_CHECK = bool(__import__("os").environ.get("MI3DGS_NAN_CHECK"))
 
 
 @dataclasses.dataclass
@@ -75,7 +76,18 @@ class MCMCTrainer(Trainer):
     @torch.no_grad()
     def step(self, view_index: int, want_loss: bool = False):
         step = self.step_count
+        if _NAN_CHECK and not getattr(self, "_nan_seen", False):
+            self._prev = {g: self._rows(g)[: self.model.n].clone() for g in GROUPS}
+            self._prev_mv = {g: (self.model.state(g, "m")[: self.model.n].clone(), self.model.state(g, "v")[: self.model.n].clone()) for g in ("means", "scales")}
         out = super().step(view_index, want_loss)
+        if _NAN_CHECK and not getattr(self, "_nan_seen", False):
+            bad = ~torch.isfinite(self._rows("means")[: self.model.n]).all(1)
+            if bool(bad.any()):
+                i = int(torch.nonzero(bad).flatten()[0])
+                print(f"[nan-check] step {step} view {view_index} BEFORE noise/refine: row {i}: prev means {self._prev['means'][i].tolist()} quats {self._prev['quats'][i].tolist()} "
+                      f"log-scales {self._prev['scales'][i].tolist()} opac {self._prev['opacities'][i].tolist()}\n   grads: means {self.model.grad('means')[i].tolist()} quats {self.model.grad('quats')[i].tolist()} "
+                      f"scales {self.model.grad('scales')[i].tolist()} opac {self.model.grad('opacities')[i].tolist()}\n   radii {self.radii[0, i].tolist()} record {self.splats[0, i].tolist()}\n   vrecord {self.v_splats[0, i].tolist()}"
+                      f"\n   prev m/v means {self._prev_mv['means'][0][i].tolist()} {self._prev_mv['means'][1][i].tolist()} viewmat {self.viewmats[view_index].tolist()}", flush=True)
         c, m = self.mcmc, self.model
         if c.refine_start_iter < step < c.refine_stop_iter and step % c.refine_every == 0:
             self.mcmc_totals["relocated"] += self.relocate()
@@ -85,6 +97,14 @@ class MCMCTrainer(Trainer):
         ops._lib.call("mi3dgs_mcmc_inject_noise", m.n, ops._p(m.p("means")), ops._p(m.p("quats")), ops._p(m.p("scales")),
                       ops._p(m.p("opacities")), float(lr_means * c.noise_lr), seed, ops._stream(self.device))
         self.refine_totals = dict(n_dup=self.mcmc_totals["added"], n_split=self.mcmc_totals["relocated"], n_prune=0)
+        if _NAN_CHECK and not getattr(self, "_nan_seen", False):
+            for g in GROUPS:
+                bad = ~torch.isfinite(self._rows(g)[: m.n]).reshape(m.n, -1).all(1)
+                if bool(bad.any()):
+                    idx = torch.nonzero(bad).flatten()[:5].tolist()
+                    print(f"[nan-check] step {step}: {int(bad.sum())} non-finite rows in {g}, first {idx}; refine step: {step % c.refine_every == 0}; "
+                          f"opacity logits {self._rows('opacities')[idx, 0].tolist()} scales {self._rows('scales')[idx].tolist()}", flush=True)
+                    self._nan_seen = True
         return out
 
     # -- helpers -------------------------------------------------------------------

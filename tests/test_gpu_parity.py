@@ -388,6 +388,39 @@ def test_training_recovers_target(dev):
     assert last < 0.5 * first, (first, last)
 
 
+@pytest.mark.parametrize("two_cams", [False, True])
+@pytest.mark.parametrize("vgrad", [0.0, 1e-3])
+def test_projection_backward_stays_finite_on_a_needle_gaussian(dev, two_cams, vgrad):
+    """Found in the MCMC synthetic run (tools/nan_probe.py): a needle-thin Gaussian 0.09 in front of the camera, projecting
+    thousands of pixels wide, has a 2D determinant that is all rounding; the training kernel recomputed it, got 0 where the
+    forward had got a small positive number, and 0 * inf made every geometric gradient NaN even with an all-zero gradient
+    record -- for good, since Adam keeps a NaN.  The backward now takes the conic the forward stored."""
+    ops = _ops()
+    means = torch.tensor([[-0.5355250835418701, -0.0883798897266388, -1.2471290826797485]], device=dev)
+    quats = torch.tensor([[1.1715995073318481, 1.1246978044509888, 0.7527013421058655, 0.2929958701133728]], device=dev)
+    scales = torch.tensor([[-17.504308700561523, -0.5044186115264893, -3.654362201690674]], device=dev)
+    opac = torch.tensor([-3.7583377361297607], device=dev)
+    sh0, shN = torch.zeros(1, 1, 3, device=dev), torch.zeros(1, 15, 3, device=dev)
+    vm = torch.tensor([[[0.07606703788042068, 0.9971022605895996, 0.0009645117679610848, 0.0006943568005226552],
+                        [-0.3021939992904663, 0.022131966426968575, 0.9529894590377808, -0.0068558864295482635],
+                        [0.9502065777778625, -0.07278256118297577, 0.3030018210411072, 0.9749422073364258],
+                        [0.0, 0.0, 0.0, 1.0]]], device=dev)
+    K = torch.tensor([[[725.0, 0, 480.0], [0, 725.0, 270.0], [0, 0, 1]]], device=dev)
+    if two_cams:                                   # the generic (any number of cameras) kernel
+        vm, K = vm.repeat(2, 1, 1), K.repeat(2, 1, 1)
+    radii, splats = ops.project_fwd(means, quats, scales, opac, vm, K, 960, 540, sh0=sh0, shN=shN, sh_degree=3, flags=3)
+    assert bool((radii > 1000).all())              # visible, and enormous
+    v = torch.full((vm.shape[0], 1, 16), vgrad, device=dev)
+    out = ops.project_bwd(means, quats, scales, opac, vm, K, 960, 540, radii, splats, v, sh0=sh0, shN=shN,
+                          color_mode=ops.COLOR_SH, sh_degree=3, flags=3)
+    for k, t in out.items():
+        assert bool(torch.isfinite(t).all()), k
+    if vgrad == 0.0:
+        assert all(float(out[k].abs().max()) == 0.0 for k in ("v_means", "v_quats", "v_scales"))
+    else:
+        assert float(out["v_means"].abs().max()) > 0
+
+
 def test_auto_isect_capacity_follows_the_exact_path_and_grows_on_overflow(dev):
     """TrainConfig.auto_isect_capacity (what the ns-train / simple_trainer shims run with): tile-list buffers sized from
     measured counts so that no step reads the count back.  Same training as the exact (count read back every step) path up
