@@ -122,6 +122,10 @@ class MCMCTrainer(Trainer):
         sc = torch.exp(self._rows("scales")[sampled])
         counts = torch.bincount(sampled, minlength=m.n)[sampled] + 1
         no, ns = compute_relocation(op, sc, counts.clamp(max=N_MAX), self.binoms)
+        # (the alternating binomial sum of the scale formula cancels in float32 for large ratios: keep the old scale rather than
+        #  the logarithm of a non-positive number)
+        ns = torch.where(torch.isfinite(ns) & (ns > 0), ns, sc)
+        no = torch.where(torch.isfinite(no), no, op)
         no = no.clamp(min=c.min_opacity, max=1.0 - 1e-7)
         self._rows("opacities")[sampled, 0] = torch.log(no / (1.0 - no))
         self._rows("scales")[sampled] = torch.log(ns)
