@@ -1039,6 +1039,16 @@ struct WaveEmitLds {
     unsigned long long bitmap[WE_GROUPS];
 };
 
+// SPW = splats per wave: 64, or 16 for small scenes (a wave's items are walked 64 at a time, serially: at 20 k big Gaussians
+// and 1080p a 64-splat wave has thousands of tile rows and the whole launch is 313 waves).
+inline uint32_t we_small_splats() {
+    static const uint32_t v = [] { const char* e = getenv("MI3DGS_EMIT_SMALL_SPLATS"); return e ? (uint32_t)atol(e) : (128u << 10); }();
+    return v;
+}
+inline int we_spw_for(uint32_t CN) { return CN <= we_small_splats() ? 16 : 64; }
+inline size_t we_chain_entries(uint32_t CN) { return (size_t)WE_WAVES * (size_t)mi_div_up(CN, (long long)we_spw_for(CN) * WE_WAVES); }
+
+template <int SPW>
 __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     uint32_t CN_cap, const uint32_t* __restrict__ n_sorted_ptr, bool radii_in_records, uint32_t N,
     const uint32_t* __restrict__ sorted_ids, const int32_t* __restrict__ radii, const float* __restrict__ splats, int tile_size,
@@ -1058,8 +1068,9 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     __syncthreads();
     const uint32_t CN = live_count(n_sorted_ptr, CN_cap);
     const uint32_t wid = s_blk * (uint32_t)WE_WAVES + (threadIdx.x >> 6);
-    if (wid * 64u >= CN) return;              // past the end of the sorted list
-    const uint32_t i = wid * 64u + (uint32_t)lane;
+    if (wid * (uint32_t)SPW >= CN) return;    // past the end of the sorted list
+    const uint32_t i = wid * (uint32_t)SPW + (uint32_t)lane;
+    const bool owns = lane < SPW && i < CN;   // this lane brings in a splat
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t idx = 0, rows = 0;
     {
@@ -1068,7 +1079,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         geo.x0 = geo.y0 = geo.x1 = geo.y1 = 0;
         geo.exact = false;
         uint32_t kc = 0;
-        if (i < CN) {
+        if (owns) {
             idx = sorted_ids[i];
             const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
             int2 r = radii_in_records ? make_int2(__float_as_int(sp[SP_RX]), __float_as_int(sp[SP_RY]))
@@ -1090,15 +1101,15 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     const uint32_t rincl = wave_incl_scan_u32(rows);
     L.row_base[lane] = rincl - rows;
     const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
-    if (lane == 63) L.row_base[64] = R;
+    if (lane == 63) L.row_base[SPW] = R;      // (lanes >= SPW carry no rows: their prefix is R as well)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // same-wave LDS hand-off
     __builtin_amdgcn_wave_barrier();
 
     // item j -> (owner splat g, tx0 | len << 16)
     auto eval_item = [&](uint32_t j, uint32_t& g, uint32_t& span) {
-        uint32_t lo = 0, hi = 63;                  // largest g with row_base[g] <= j (splats without rows share a prefix with their successor)
+        uint32_t lo = 0, hi = SPW - 1;             // largest g with row_base[g] <= j (splats without rows share a prefix with their successor)
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
+        for (int it = 0; it < (SPW == 64 ? 6 : 4); it++) {
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (L.row_base[mid] <= j) lo = mid; else hi = mid - 1;
         }
@@ -1131,7 +1142,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     const uint32_t total = wave_sum_u32(mine);
     // ---- chain
     const uint32_t base = chain_lookback(status, wid, total, lane, chain_err);
-    if (wid == (CN - 1u) / 64u && lane == 0) {
+    if (wid == (CN - 1u) / (uint32_t)SPW && lane == 0) {
         uint32_t tot = base + total;
         if (tot > cap) { atomicOr(chain_err, 4u); tot = cap; }
         *n_isect_out = tot;
@@ -1139,7 +1150,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     if (tiles_out) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (i < CN) tiles_out[idx] = L.cnt[lane];
+        if (owns) tiles_out[idx] = L.cnt[lane];
     }
     // ---- emit
     uint32_t running = 0;                            // outputs of the chunks before this one (wave-local)
@@ -1315,7 +1326,7 @@ size_t bin_zero_layout(uint32_t CN, uint32_t cap, uint32_t* base, BinZero* z);
 size_t bin_zero_layout(uint32_t CN, uint32_t cap, uint32_t* base, BinZero* z) {
     size_t o = 0;
     auto take = [&](size_t n) { uint32_t* p = base ? base + o : nullptr; o += align_u32(n); return p; };
-    const size_t nchain = (size_t)WE_WAVES * (size_t)mi_div_up(CN, 64 * WE_WAVES);
+    const size_t nchain = we_chain_entries(CN);
     uint32_t* n_live = take(16);
     uint32_t* chain = take(2 * nchain + 16);
     uint32_t* depth = take(rs_zero_u32(CN, 32));
@@ -1507,7 +1518,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     const uint32_t* sorted_ids = in_b ? ws.ids_b : ws.ids_a;
     // chain state: status[nchain] u64 | counter | slow count, in the pre-cleared control block
     uint32_t nblocks = (uint32_t)mi_div_up(CN, 256);
-    const uint32_t nchain = (uint32_t)WE_WAVES * (uint32_t)mi_div_up(CN, 64 * WE_WAVES);   // one status word per 64-splat chunk (>= nblocks)
+    const uint32_t nchain = (uint32_t)we_chain_entries(CN);   // one status word per wave of the wave-granular emit (>= nblocks)
     unsigned long long* status = reinterpret_cast<unsigned long long*>(z.chain);
     uint32_t* counter = z.chain + 2 * (size_t)nchain;
     uint32_t* err = async_err_ptr();
@@ -1516,8 +1527,12 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     const bool wave_emit = tight && g_emit_mode == 1 && tile_width <= WE_GROUPS;
-    if (wave_emit)
-        MI_LAUNCH("tile_emit", tile_emit_wave_kernel, dim3(mi_div_up(CN, 64 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
+    if (wave_emit && we_spw_for(CN) == 16)
+        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<16>, dim3(mi_div_up(CN, 16 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
+                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    else if (wave_emit)
+        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<64>, dim3(mi_div_up(CN, 64 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
     else if (tight)
