@@ -46,30 +46,45 @@ __device__ __forceinline__ float block_sum(float v, float* lds4) {
 // padded), in two steps: ALL global loads of a thread first (into registers), the LDS stores after.
 // The one-step version compiled to load -> s_waitcnt vmcnt(0) -> ds_write per element, i.e. eleven
 // full memory latencies in series per image and block.
-constexpr int ST_ITERS = (LW * ROW3 + NT - 1) / NT;     // elements of one image per thread
+// Thread -> (row group, float of the row): 126 floats of a staged row fit 128 lanes, so a thread keeps ONE column (its
+// channel, its LDS column and its bounds test against the image width are computed once) and walks rows rgrp, rgrp + 4, ...:
+// per element an add, two compares and the load.  The first version flattened (row, float) into one index and paid a division
+// by 126, a division by 3 and five compares per element: 17 % of loss_fwd's and 40 % of loss_bwd's vector instructions.
+constexpr int ST_COLS = 128;                             // lanes per staged row (126 used)
+constexpr int ST_RGRP = NT / ST_COLS;                    // rows in flight per iteration
+constexpr int ST_ITERS = (LW + ST_RGRP - 1) / ST_RGRP;   // iterations per image
+static_assert(ROW3 <= ST_COLS && NT % ST_COLS == 0, "staging layout");
 
-__device__ __forceinline__ void stage_load(const float* __restrict__ img, int H, int W, int x0, int y0,
+struct StageCol { int j, rgrp, xj, col, ch; bool xok; };
+
+__device__ __forceinline__ StageCol stage_col(int W, int x0) {
+    StageCol c;
+    c.j = (int)threadIdx.x & (ST_COLS - 1);
+    c.rgrp = (int)threadIdx.x / ST_COLS;
+    c.xj = (x0 - HALO) * 3 + c.j;                        // float index inside the image row: 3 x + channel
+    c.col = c.j / 3;
+    c.ch = c.j - 3 * c.col;
+    c.xok = c.j < ROW3 && c.xj >= 0 && c.xj < W * 3;
+    return c;
+}
+
+__device__ __forceinline__ void stage_load(const float* __restrict__ img, int H, int W, int y0, const StageCol& c,
                                            float (&v)[ST_ITERS]) {
 #pragma unroll
     for (int it = 0; it < ST_ITERS; it++) {
-        int i = (int)threadIdx.x + it * NT;
-        int r = i / ROW3, j = i - r * ROW3;
-        int y = y0 + r - HALO;
-        int xj = (x0 - HALO) * 3 + j;                      // float index inside the image row: 3 x + channel
-        bool ok = i < LW * ROW3 && y >= 0 && y < H && xj >= 0 && xj < W * 3;
-        int off = ok ? y * (W * 3) + xj : 0;              // 32-bit offset from a uniform base: saddr addressing, one VGPR
-        float val = img[off];
+        const int y = y0 + it * ST_RGRP + c.rgrp - HALO;
+        const bool ok = c.xok && y >= 0 && y < H;
+        const int off = ok ? y * (W * 3) + c.xj : 0;      // 32-bit offset from a uniform base: saddr addressing, one VGPR
+        const float val = img[off];
         v[it] = ok ? val : 0.f;
     }
 }
 
-__device__ __forceinline__ void stage_store(float (*plane)[LW][LS], const float (&v)[ST_ITERS]) {
+__device__ __forceinline__ void stage_store(float (*plane)[LW][LS], const StageCol& c, const float (&v)[ST_ITERS]) {
 #pragma unroll
     for (int it = 0; it < ST_ITERS; it++) {
-        int i = (int)threadIdx.x + it * NT;
-        int r = i / ROW3, j = i - r * ROW3;
-        int col = j / 3, ch = j - col * 3;
-        if (i < LW * ROW3) plane[ch][r][col] = v[it];
+        const int r = it * ST_RGRP + c.rgrp;
+        if (c.j < ROW3 && r < LW) plane[c.ch][r][c.col] = v[it];
     }
 }
 
@@ -91,11 +106,12 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const size_t base = (size_t)cam * H * W * 3;
     {
+        const StageCol sc = stage_col(W, x0);
         float ra[ST_ITERS], rb[ST_ITERS];
-        stage_load(img1 + base, H, W, x0, y0, ra);
-        stage_load(img2 + base, H, W, x0, y0, rb);
-        stage_store(pu, ra);
-        stage_store(pv, rb);
+        stage_load(img1 + base, H, W, y0, sc, ra);
+        stage_load(img2 + base, H, W, y0, sc, rb);
+        stage_store(pu, sc, ra);
+        stage_store(pv, sc, rb);
     }
     __syncthreads();
     const int vc = threadIdx.x & 31, vg = threadIdx.x >> 5;      // vertical pass: column, row group
@@ -103,16 +119,19 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
     for (int ch = 0; ch < 3; ch++) {
         for (int t = threadIdx.x; t < LW * (LT / 4); t += NT) {
             int r = t >> 3, c0 = (t & 7) * 4;
-            float u[14], v[14];
+            float u[14], v[14], uu[14], vv[14], uv[14];
 #pragma unroll
             for (int k = 0; k < 14; k++) { u[k] = pu[ch][r][c0 + k]; v[k] = pv[ch][r][c0 + k]; }
+            // the three products once per staged value (42 multiplies), not once per (output, tap) pair (88 + 44)
+#pragma unroll
+            for (int k = 0; k < 14; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
-                    float w = GW[k], a = u[o + k], b = v[o + k];
-                    s1 += w * a; s2 += w * b; s11 += w * a * a; s22 += w * b * b; s12 += w * a * b;
+                    const float w = GW[k];
+                    s1 += w * u[o + k]; s2 += w * v[o + k]; s11 += w * uu[o + k]; s22 += w * vv[o + k]; s12 += w * uv[o + k];
                 }
                 hz[0][r][c0 + o] = s1; hz[1][r][c0 + o] = s2; hz[2][r][c0 + o] = s11; hz[3][r][c0 + o] = s22;
                 hz[4][r][c0 + o] = s12;
@@ -182,10 +201,11 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
     const size_t base = (size_t)cam * H * W * 3;
     // every global read of the block goes out first: the three derivative maps and the two image
     // values of each output pixel
+    const StageCol sc = stage_col(W, x0);
     float rm[3][ST_ITERS];
-    stage_load(dm_dmu1 + base, H, W, x0, y0, rm[0]);
-    stage_load(dm_dsig1 + base, H, W, x0, y0, rm[1]);
-    stage_load(dm_dsig12 + base, H, W, x0, y0, rm[2]);
+    stage_load(dm_dmu1 + base, H, W, y0, sc, rm[0]);
+    stage_load(dm_dsig1 + base, H, W, y0, sc, rm[1]);
+    stage_load(dm_dsig12 + base, H, W, y0, sc, rm[2]);
     const int vc = threadIdx.x & 31, vg = threadIdx.x >> 5;
     float pu_[3][VO], pv_[3][VO];
 #pragma unroll
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
 #pragma unroll
     for (int m = 0; m < 3; m++) {
         __syncthreads();
-        stage_store(pl, rm[m]);
+        stage_store(pl, sc, rm[m]);
         __syncthreads();
         for (int t = threadIdx.x; t < 3 * LW * (LT / 4); t += NT) {
             int ch = t / (LW * (LT / 4));
