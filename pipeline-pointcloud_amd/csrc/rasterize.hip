@@ -328,7 +328,7 @@ extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
     // forward with the next sub-batch's MFMAs issued before the current one is composited (137 -> 173 us: 96 instead of 64
     // VGPRs), backward with the tile list fetched one batch ahead (no change; in the forward 136.6 -> 149.5 us),
     // 3 = MFMA forward, backward with the cross-lane reduce-scatter instead of the MFMA contraction
-    g_raster_mode = (mode < 0 || (mode > 3 && (mode < 11 || mode > 13))) ? 1 : mode;     // 11..13: timing experiments
+    g_raster_mode = (mode < 0 || (mode > 3 && (mode < 11 || mode > 14))) ? 1 : mode;     // 11..13: timing experiments, 14: wave-flush variant
     return 0;
 }
 

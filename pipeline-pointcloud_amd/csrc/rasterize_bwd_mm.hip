@@ -76,6 +76,8 @@ struct MMPend {
     u4v a[4];
     f4v d;
     int slot0;                // first slot of the chunk inside its group
+    int slot_abs;             // ... inside the staged batch (wave-flush variant)
+    unsigned live;            // ... which of its visits were live (wave-flush variant)
     bool on;                  // wave-uniform
 };
 
@@ -83,14 +85,50 @@ __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
     P.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, P.a[m]), __builtin_bit_cast(bf8v, mm.bop[m]), P.d, 0, 0, 0);
 }
 
-template <bool ABSGRAD>
-__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv) {
+// WF (variant, MI3DGS_RASTER_MODE=14): the wave turns its own chunk's sums into gradient records and adds them to global
+// memory itself -- no per-wave sums kept for a block flush, no group barriers, but one 64-byte float-atomic request per
+// (quadrant, splat) instead of one per (tile, splat).
+template <bool ABSGRAD, bool WF>
+__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
+                                          float* __restrict__ v_splats) {
     constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
+    constexpr int CH = ABSGRAD ? 4 : 8;
     if (mm.acc_off >= 0) {
-        float* a = &L.accw[wv][P.slot0][0] + mm.acc_off;
+        float* a = &L.accw[wv][WF ? 0 : P.slot0][0] + mm.acc_off;
         a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3];
     }
     P.on = false;
+    if (WF) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // same-wave LDS hand-off
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < CH / 4; q++) {
+            const int sc = 4 * q + (lane >> 4), comp = lane & 15;
+            const bool lv = (P.live >> sc) & 1u;
+            if (lv && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
+                const float* ac = L.accw[wv][sc];
+                const int slot = P.slot_abs + sc;
+                const float M = ac[AC_Q], Mu = ac[AC_QU], Mv = ac[AC_QV];
+                const float4 ge = L.geo[slot];
+                const float2 g2 = L.geo2[slot];
+                const float mx = ge.x, my = ge.y;
+                const float sdx = mx * M - Mu, sdy = my * M - Mv;
+                float val;
+                switch (comp) {
+                    case GR_X: val = -(ge.z * sdx + ge.w * sdy); break;
+                    case GR_Y: val = -(ge.w * sdx + g2.x * sdy); break;
+                    case GR_CA: val = -0.5f * (mx * (mx * M - 2.f * Mu) + ac[AC_QUU]); break;
+                    case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + ac[AC_QUV]); break;
+                    case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + ac[AC_QVV]); break;
+                    case GR_OPA: val = M * g2.y; break;
+                    case GR_R: case GR_G: case GR_B: val = ac[comp] + ac[comp + 3]; break;
+                    case GR_ABSX: val = ac[AW_ABSX < AW ? AW_ABSX : 0]; break;
+                    default: val = ac[AW_ABSY < AW ? AW_ABSY : 0]; break;
+                }
+                atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
+            }
+        }
+    }
 }
 
 template <bool ABSGRAD>
@@ -104,12 +142,13 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int 
     P.on = true;
 }
 
-template <bool ABSGRAD>
-__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv) {
+template <bool ABSGRAD, bool WF>
+__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
+                                         float* __restrict__ v_splats) {
     if (!P.on) return;
 #pragma unroll
     for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
-    mm_finish(L, P, mm, wv);
+    mm_finish<ABSGRAD, WF>(L, P, mm, wv, lane, v_splats);
 }
 
 // One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
@@ -119,7 +158,8 @@ template <bool ABSGRAD, bool FAST, int EXP>
 __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
                                                  int bin_final, unsigned long long has, const PixelBasis& px, const MMLane& mm,
                                                  MMPend& P, unsigned long long& gmask, const float (&vrgb)[3], float tail,
-                                                 float& T, float& bufdot) {
+                                                 float& T, float& bufdot, float* __restrict__ v_splats) {
+    constexpr bool WF = (EXP & 4) != 0;
     constexpr int CH = ABSGRAD ? 4 : 8;          // splats per chunk: CH x (2 or 4 values) = 16 rows
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
@@ -171,8 +211,13 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
             }
         }
         if (ci == CH - 1) {
-            if (P.on) mm_finish(L, P, mm, wv);
-            if ((live >> (i - (CH - 1))) & ((1u << CH) - 1u)) mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
+            if (P.on) mm_finish<ABSGRAD, WF>(L, P, mm, wv, lane, v_splats);
+            const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
+            if (cl) {
+                mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
+                P.slot_abs = k - (CH - 1);
+                P.live = cl;
+            }
         }
     }
     gmask |= (unsigned long long)live << gs0;
@@ -307,12 +352,12 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
                 float s[SUB];
                 eval_sub_batch(L.f, sb, lane, basis, s);
                 if (be - sb * SUB <= wmin)
-                    bwd_sub_batch_mm<ABSGRAD, true, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot);
+                    bwd_sub_batch_mm<ABSGRAD, true, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
                 else
-                    bwd_sub_batch_mm<ABSGRAD, false, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot);
+                    bwd_sub_batch_mm<ABSGRAD, false, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
             }
-            mm_drain(L, P, mm, wv);
-            if (EXP & 1) continue;          // timing experiment: no group barriers, no flush
+            mm_drain<ABSGRAD, (EXP & 4) != 0>(L, P, mm, wv, lane, v_splats);
+            if (EXP & 5) continue;          // 1: timing experiment, no group barriers, no flush; 4: the waves have flushed themselves
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
             // flush: lane -> (slot = lane >> 4, column = lane & 15), 16 slots per round over the block.  A wave's 4 slots lie in
@@ -382,7 +427,10 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats)
-    if (experiment != 0 && !backgrounds && !absgrad) {
+    if (experiment == 4) {           // wave-flush variant (correct results)
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4); else LAUNCH_MM(true, false, 4); }
+        else { if (absgrad) LAUNCH_MM(false, true, 4); else LAUNCH_MM(false, false, 4); }
+    } else if (experiment != 0 && !backgrounds && !absgrad) {
         if (experiment == 1) LAUNCH_MM(false, false, 1);
         else if (experiment == 2) LAUNCH_MM(false, false, 2);
         else LAUNCH_MM(false, false, 3);
