@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
             if (v_opacities) v_opacities[n] = G.vopa;
             v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
-        } else {
+        } else if (!(flags & 64)) {      // (flags bit 6 / 7: timing experiments only, skip the small groups' / the shN Adam)
             // ---- Adam on the five small groups, one thread per Gaussian
             float sl[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
             if (A.sreg_weight > 0.f) {
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (!FUSE) {
         slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
-    } else {
+    } else if (!(flags & 128)) {
         // ---- Adam on the wave's shN slice: gradients from LDS, p / m / v streamed with 16-byte accesses
         const long long off = 45 * (long long)n0;
         const int n4 = count >> 2;

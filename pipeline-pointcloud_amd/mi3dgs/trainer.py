@@ -20,6 +20,7 @@ import torch
 from . import ops
 
 GROUPS = ("means", "quats", "scales", "opacities", "sh0", "shN")
+_EXPERIMENT_FLAGS = int(__import__("os").environ.get("MI3DGS_BWD_EXPERIMENT", "0"))     # timing experiments of project_bwd_adam (wrong results)
 WIDTHS = (3, 4, 3, 1, 3, 45)
 _SHAPES = {"means": (3,), "quats": (4,), "scales": (3,), "opacities": (), "sh0": (1, 3), "shN": (15, 3)}
 
@@ -197,7 +198,7 @@ class Trainer:
         f = ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC
         if self.cfg.antialiased:
             f |= ops.FLAG_ANTIALIASED
-        return f
+        return f | _EXPERIMENT_FLAGS
 
     def downscale_now(self) -> int:
         c = self.cfg
