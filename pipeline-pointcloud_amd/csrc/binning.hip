@@ -263,7 +263,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
         if (run) atomicAdd(&h[run_d], run);
     }
     __syncthreads();
-    hist[threadIdx.x * B + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x <= mask) hist[threadIdx.x * B + blockIdx.x] = h[threadIdx.x];      // (rows of digits this pass does not have are never read)
 }
 
 // BITS = width of this pass's digit: the match-any ranking below costs one ballot + a 64-bit per-lane select per
@@ -626,8 +626,10 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         uint32_t mask = (1u << bits) - 1u;
         MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
         // (pre-cleared scan scratch: one region per pass)
-        int rc = zeroed ? scan_exclusive_u32(hist, hist, 256u * B, zeroed + (size_t)p * align_u32(scan_tmp_u32((size_t)256 * B)), nullptr, st, s0, true)
-                        : scan_exclusive_u32(hist, hist, 256u * B, scan_tmp, nullptr, st, s0);
+        // (digit-major histogram: the digits this pass does not have are zeros at its tail and need no scanning)
+        const uint32_t nscan = (mask + 1u) * B;
+        int rc = zeroed ? scan_exclusive_u32(hist, hist, nscan, zeroed + (size_t)p * align_u32(scan_tmp_u32((size_t)256 * B)), nullptr, st, s0, true)
+                        : scan_exclusive_u32(hist, hist, nscan, scan_tmp, nullptr, st, s0);
         if (rc) return rc;
 #define RS_SCATTER(NB) MI_LAUNCH(ctag, rs_scatter_kernel<NB>, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, \
                                  n_ptr, cap, shift, mask, hist, B)
