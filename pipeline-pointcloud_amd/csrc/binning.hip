@@ -1047,7 +1047,10 @@ inline uint32_t we_small_splats() {
     static const uint32_t v = [] { const char* e = getenv("MI3DGS_EMIT_SMALL_SPLATS"); return e ? (uint32_t)atol(e) : (128u << 10); }();
     return v;
 }
-inline int we_spw_for(uint32_t CN) { return CN <= we_small_splats() ? 16 : 64; }
+inline int we_spw_for(uint32_t CN) {
+    static const int big = [] { const char* e = getenv("MI3DGS_EMIT_SPW"); int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
+    return CN <= we_small_splats() ? 16 : big;
+}
 inline size_t we_chain_entries(uint32_t CN) { return (size_t)WE_WAVES * (size_t)mi_div_up(CN, (long long)we_spw_for(CN) * WE_WAVES); }
 
 template <int SPW>
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     auto eval_item = [&](uint32_t j, uint32_t& g, uint32_t& span) {
         uint32_t lo = 0, hi = SPW - 1;             // largest g with row_base[g] <= j (splats without rows share a prefix with their successor)
 #pragma unroll
-        for (int it = 0; it < (SPW == 64 ? 6 : 4); it++) {
+        for (int it = 0; it < (SPW == 64 ? 6 : SPW == 32 ? 5 : 4); it++) {
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (L.row_base[mid] <= j) lo = mid; else hi = mid - 1;
         }
@@ -1531,6 +1534,10 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     const bool wave_emit = tight && g_emit_mode == 1 && tile_width <= WE_GROUPS;
     if (wave_emit && we_spw_for(CN) == 16)
         MI_LAUNCH("tile_emit", tile_emit_wave_kernel<16>, dim3(mi_div_up(CN, 16 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
+                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
+                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    else if (wave_emit && we_spw_for(CN) == 32)
+        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<32>, dim3(mi_div_up(CN, 32 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
                   (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
     else if (wave_emit)
