@@ -1,17 +1,18 @@
-// Tile rasteriser, forward and backward, with the pixel x splat quadratic forms on the MATRIX pipe.
+// Tile rasteriser: the forward kernel and the reduce-scatter backward kernel (the A/B partner of rasterize_bwd_mm.hip, which is
+// the product backward), both with the pixel x splat quadratic forms on the MATRIX pipe (rasterize_mfma.h).
 // gfx950 only.  Replaces gsplat rasterize_to_pixels_{fwd,bwd}, reached by the
 // reference only through main.py:1312 / main.py:1343.
 //
 // What is a matrix product here.  For a pixel p of a tile and a splat s of its list
 //     log2 alpha(s, p) = log2 o_s - log2e * sigma(s, p)
 //                      = c0 u^2 + c1 uv + c2 v^2 + c3 u + c4 v + c5,     (u, v) = p - tile centre,
-// a [32 splats x 6] . [6 x 64 pixels] product with NO padding in K on v_mfma_f32_32x32x2_f32 (K = 2 per
-// instruction, three accumulating instructions per 32 pixels): 12 matrix-pipe cycles per (wave, splat)
-// visit beside the vector pipe, instead of the 5 (backward: 7) VALU instructions per visit that evaluated
-// dx, dy and the conic.  Both rasterisers were 100 % VALU-issue bound (round 1, DESIGN.md finding 16).
+// a [32 splats x 6] . [6 x 64 pixels] product.  Round 2 first ran it on v_mfma_f32_32x32x2_f32; an f32-input MFMA turned
+// out to occupy the vector ALUs for its whole duration (DESIGN.md finding 25), so it now runs as two
+// v_mfma_f32_32x32x16_bf16 per 32 pixels with every coefficient in three bf16 terms and a basis that is exact in bf16
+// (rasterize_mfma.h: the same sums in f32, 24 significant bits per coefficient).
 // The six coefficients are computed once per (tile, splat) when the record is staged into LDS
-// (quad_coefs, tile-centre coordinates keep |u|, |v| <= 7.5 so the f32 chain cancels to ~2e-4 in log2
-// units at worst); the per-pixel basis is six registers per lane for the whole kernel.
+// (quad_coefs, tile-centre coordinates keep |u|, |v| <= 7.5 so the f32 chain cancels to ~4e-4 in log2
+// units at worst); the per-pixel basis is ten registers per lane for the whole kernel.
 //
 // Layout.  A = coefficients (row = splat), B = basis (column = pixel).  The C/D map of 32x32 puts one pixel
 // COLUMN on a lane and 16 of the 32 splat ROWS in its registers, the other 16 rows of the same pixel on
@@ -20,12 +21,12 @@
 // owns one pixel and holds all 32 splats of the sub-batch in 32 registers, statically indexed.  The
 // front-to-back chain then runs out of registers.
 //
-// Forward and backward evaluate log2 alpha through the SAME instruction sequence (quad_coefs -> the
-// same three MFMAs -> v_min3 -> v_exp), so the backward's membership test alpha >= 1/255 is the forward's
+// Forward and backward evaluate log2 alpha through the SAME instruction sequence (quad_coefs -> split3 -> the
+// same four MFMAs -> v_min -> v_exp), so the backward's membership test alpha >= 1/255 is the forward's
 // bit for bit (round 1 used exp2 of a pre-scaled conic forward and __expf backward).
 //
-// Backward: what is reduced over the pixels of a quadrant per splat is q = -dL/dsigma and its five
-// moments q u, q v, q u^2, q uv, q v^2 plus the three colour sums (9 values, one reduce-scatter as before);
+// Backward (this file's kernel): what is reduced over the pixels of a quadrant per splat is q = -dL/dsigma and its five
+// moments q u, q v, q u^2, q uv, q v^2 plus the three colour sums (9 values, one cross-lane reduce-scatter per live visit);
 // the conic / mean / opacity gradients follow per (tile, splat) from the moments at flush time, so the per-pair
 // products dx^2, dx dy, A dx + B dy ... are gone from the inner loop.
 
