@@ -117,6 +117,35 @@ __device__ __forceinline__ uint32_t chain_lookback(unsigned long long* status, u
     return excl;
 }
 
+// The look-back alone: exclusive prefix of the entries before `blk` (entries publish themselves elsewhere).
+__device__ __forceinline__ uint32_t chain_prefix_before(const unsigned long long* status, uint32_t blk, int lane, uint32_t* err) {
+    uint32_t excl = 0;
+    int p = (int)blk - 1;
+    while (p >= 0) {
+        int idx = p - lane;
+        unsigned long long w = chain_pack(2u, 0u);              // before entry 0: prefix 0
+        if (idx >= 0) {
+            unsigned spins = 0;
+            while (true) {
+                w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((w >> 32) & 3ull) != 0ull) break;
+                if (++spins > CHAIN_SPIN_LIMIT) { atomicOr(err, 2u); w = chain_pack(2u, 0u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const uint32_t val = (uint32_t)w;
+        const unsigned long long pm = wave_ballot(((w >> 32) & 3ull) == 2ull);
+        if (pm) {
+            const int f = __ffsll((long long)pm) - 1;            // nearest predecessor holding a prefix
+            excl += wave_sum_u32(lane <= f ? val : 0u);
+            break;
+        }
+        excl += wave_sum_u32(val);
+        p -= 64;
+    }
+    return excl;
+}
+
 // Device-wide exclusive scan in ONE launch: a block scans its 4 096-element tile in registers, chains
 // its total through `status` (decoupled look-back) and writes.  Replaces reduce / scan-of-sums /
 // final (three launches, ~30 us for the 950 k block-histogram counters of a radix pass).
@@ -1069,11 +1098,41 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     // 16 b + w; all 16 run concurrently, so every predecessor of a chain entry belongs to a block that has started and
     // publishes its aggregate without waiting for anybody.  (Several chunks per wave do NOT work: a wave could publish the
     // aggregate of its second chunk only after its first chunk's look-back, which serialises the whole chain: 115 ms.)
-    if (threadIdx.x == 0) s_blk = atomicAdd(chain_counter, 1u);
+    // The chain is TWO-LEVEL.  All 8 192 waves the GPU holds start together, so with one chain entry per wave a wave's look-back
+    // never met an inclusive prefix (those appear behind its walking front): wave w walked all w / 64 windows.  The chain
+    // entry is the BLOCK (16 waves) instead (S1 45 -> 40 us, 20 k big Gaussians at 1080p 55 -> 51 us, S2 unchanged at 157 us:
+    // running S2 without any chain takes 93 us, but that also turns its 139 MB of output into overwrites of one small region,
+    // and walking the list from its far end, so that nobody waits for the big near splats, did not help either: 172 us):
+    // the waves of a block exchange their totals through LDS (they run concurrently), the wave that arrives last publishes the
+    // block's total, wave 0 looks back over the blocks (64 of them = 1 024 waves per step), hands the block's exclusive prefix to
+    // its fifteen sisters through LDS and publishes the block's inclusive prefix.
+    __shared__ uint32_t s_tot[WE_WAVES];
+    __shared__ uint32_t s_mask, s_excl, s_excl_ready;
+    if (threadIdx.x == 0) { s_blk = atomicAdd(chain_counter, 1u); s_mask = 0u; s_excl = 0u; s_excl_ready = 0u; }
     __syncthreads();
     const uint32_t CN = live_count(n_sorted_ptr, CN_cap);
-    const uint32_t wid = s_blk * (uint32_t)WE_WAVES + (threadIdx.x >> 6);
-    if (wid * (uint32_t)SPW >= CN) return;    // past the end of the sorted list
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wid = s_blk * (uint32_t)WE_WAVES + wv;
+    // a wave arrives with its total; the one that completes the block publishes the block's total for the blocks after it
+    // (block 0 has no predecessors: that IS its inclusive prefix)
+    auto arrive = [&](uint32_t total_) {
+        constexpr uint32_t FULL_ = (1u << WE_WAVES) - 1u;
+        uint32_t old_mask = 0u;
+        if (lane == 0) {
+            s_tot[wv] = total_;
+            old_mask = __hip_atomic_fetch_or(&s_mask, 1u << wv, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        old_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)old_mask);
+        if (status && (old_mask | (1u << wv)) == FULL_) {
+            const uint32_t bt = wave_sum_u32(lane < WE_WAVES ? s_tot[lane] : 0u);
+            if (lane == 0)
+                __hip_atomic_store(status + s_blk, chain_pack(s_blk == 0 ? 2u : 1u, bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (wid * (uint32_t)SPW >= CN) {          // past the end of the sorted list: an empty member of its block
+        arrive(0u);
+        return;
+    }
     const uint32_t i = wid * (uint32_t)SPW + (uint32_t)lane;
     const bool owns = lane < SPW && i < CN;   // this lane brings in a splat
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1146,7 +1205,43 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     }
     const uint32_t total = wave_sum_u32(mine);
     // ---- chain
-    const uint32_t base = chain_lookback(status, wid, total, lane, chain_err);
+    uint32_t base = 0u;
+    if (status) {
+        constexpr uint32_t FULL = (1u << WE_WAVES) - 1u;
+        const uint32_t b = s_blk;
+        arrive(total);
+        unsigned spins = 0;
+        if (wv == 0) {
+            const uint32_t excl_b = b > 0 ? chain_prefix_before(status, b, lane, chain_err) : 0u;
+            if (lane == 0) {
+                s_excl = excl_b;
+                __hip_atomic_store(&s_excl_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (b > 0) {
+                while (__hip_atomic_load(&s_mask, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != FULL) {
+                    if (++spins > CHAIN_SPIN_LIMIT) { if (lane == 0) atomicOr(chain_err, 2u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t bt = wave_sum_u32(lane < WE_WAVES ? s_tot[lane] : 0u);
+                if (lane == 0)
+                    __hip_atomic_store(status + b, chain_pack(2u, excl_b + bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            base = excl_b;
+        } else {
+            // the totals of the waves before this one in the block, then the block's own prefix from wave 0
+            const uint32_t need = (1u << wv) - 1u;
+            while ((__hip_atomic_load(&s_mask, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & need) != need) {
+                if (++spins > CHAIN_SPIN_LIMIT) { if (lane == 0) atomicOr(chain_err, 2u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t part = wave_sum_u32((uint32_t)lane < wv ? s_tot[lane] : 0u);
+            while (__hip_atomic_load(&s_excl_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                if (++spins > CHAIN_SPIN_LIMIT) { if (lane == 0) atomicOr(chain_err, 2u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            base = s_excl + part;
+        }
+    }
     if (wid == (CN - 1u) / (uint32_t)SPW && lane == 0) {
         uint32_t tot = base + total;
         if (tot > cap) { atomicOr(chain_err, 4u); tot = cap; }
