@@ -240,8 +240,20 @@ inline uint32_t os_small_keys() {
     static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_SMALL_KEYS"); return e ? (uint32_t)atol(e) : (512u << 10); }();
     return v;
 }
-inline int os_items_for(uint32_t cap) { return cap <= os_small_keys() ? OS_ITEMS_SMALL : OS_ITEMS_BIG; }
+inline uint32_t os_nolookback() { const char* e = getenv("MI3DGS_OS_NOLOOKBACK"); return (e && e[0] == '1') ? 0x40000000u : 0u; }
+inline int os_big_items() {                        // (A/B: MI3DGS_OS_BIG_ITEMS=16 halves the big tile)
+    static const int v = [] { const char* e = getenv("MI3DGS_OS_BIG_ITEMS"); return (e && atoi(e) == 16) ? 16 : OS_ITEMS_BIG; }();
+    return v;
+}
+inline int os_items_for(uint32_t cap) { return cap <= os_small_keys() ? OS_ITEMS_SMALL : os_big_items(); }
 inline uint32_t os_tiles_for(uint32_t cap) { return (uint32_t)mi_div_up(cap, (long long)RS_THREADS * os_items_for(cap)); }
+constexpr int OS_MAX_PASSES = 4;
+constexpr int OS_GRP = 16;                            // tiles per look-back group
+// control words of a onesweep sort: ghist[4][256] | counters[8] err pad[7] | status[tiles][256] u64 | gagg[4][groups][256] u64
+inline size_t os_ctl_u32(uint32_t cap) {
+    const size_t B = os_tiles_for(cap), G = (B + OS_GRP - 1) / OS_GRP;
+    return (size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B + (size_t)512 * OS_MAX_PASSES * G;
+}
 
 __device__ __forceinline__ uint32_t live_count(const uint32_t* n_ptr, uint32_t cap) {
     if (!n_ptr) return cap;
@@ -390,8 +402,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 //   Tile ids are handed out by an atomic counter, so every predecessor of a tile belongs to a
 //   workgroup that has already started: the chain always resolves, whatever the residency.
 //   Every spin is bounded; a timeout raises *err and lets the grid drain.
-constexpr int OS_MAX_PASSES = 4;
 constexpr unsigned OS_SPIN_LIMIT = CHAIN_SPIN_LIMIT;
+constexpr int OS_LB = 8;                              // look-back loads in flight per thread
 
 // DROP: keys equal to 0xFFFFFFFF (the depth sort's "culled" sentinel) are not counted; the number of the others
 // goes to *n_live_out, and pass 0 (os_pass_kernel<DROP>) leaves them behind, so the later passes -- and
@@ -409,11 +421,18 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __r
 #pragma unroll
     for (int p = 0; p < OS_MAX_PASSES; p++) h[p][threadIdx.x] = 0;
     __syncthreads();
+    // (all loads first: one at a time, each of the OS_ITEMS rounds waited out an HBM round trip -- 25 us for 1.33 M keys)
+    uint32_t kreg[OS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+        uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+        kreg[i] = idx < n ? keys[idx] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
         uint32_t idx = base + i * RS_THREADS + threadIdx.x;
         if (idx < n) {
-            uint32_t k = keys[idx];
+            uint32_t k = kreg[i];
             if (DROP && k == 0xFFFFFFFFu) continue;
             int shift = 0;
             for (int p = 0; p < passes; p++) {
@@ -440,26 +459,64 @@ __device__ __forceinline__ unsigned long long os_pack(uint32_t epoch, uint32_t f
     return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | (unsigned long long)value;
 }
 
-template <bool DROP, int OS_ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
+#ifdef MI3DGS_OS_STAMPS
+// Probe build only (tools/sort_probe.py): wall-clock stamps (100 MHz) of the phases of every tile of the last pass run.
+__device__ unsigned long long g_os_stamps[1024][8];
+#define OS_STAMP(i) do { if (threadIdx.x == 0 && tile < 1024) g_os_stamps[tile][i] = wall_clock64(); } while (0)
+#else
+#define OS_STAMP(i) do { } while (0)
+#endif
+
+// exclusive scan over the block's first 256 threads' values (the others pass 0), NW waves in the block
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan_nw(uint32_t v, uint32_t* total, uint32_t* lds_nw) {
+    int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == 63) lds_nw[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                     // only the first four waves carry values
+        uint32_t s = lds_nw[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// One pass = one kernel.  A block of OS_THREADS (256 or 1024) threads takes a tile of OS_THREADS * OS_ITEMS keys:
+// every wave ranks its own contiguous OS_ITEMS * 64 keys (ballot match, one LDS counter row per wave), thread d < 256 owns
+// digit d (publish, look back, publish), the pairs are regrouped in LDS and leave in runs.
+// Measured with wall-clock stamps (tools/sort_probe.py, 1.33 M keys, 163 tiles of 8192 keys, 256 threads x 32 items):
+// ranking 9.4 us of a 22.5 us kernel -- 32 dependent rounds per wave with ONE wave per SIMD to hide nothing behind --,
+// look-back 4.8 us median / 6.9 max (an agent-scope load of another XCD's entry is ~0.5 us, and a tile near the end
+// needs ~10 dependent windows of 16), regroup + stores 4.4 us.  Hence 1024 threads x 8 items (8 rounds per wave, four
+// waves per SIMD) and a look-back window of OS_THREADS / 256 x OS_LB = 64 predecessors per round trip.
+template <bool DROP, int OS_THREADS, int OS_ITEMS>
+__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ ghist_pass /*[256]*/, unsigned long long* status /*[tiles][256]*/,
-    uint32_t* tile_counter, uint32_t epoch, uint32_t* err) {
-    constexpr int OS_TILE = RS_THREADS * OS_ITEMS, OS_WAVE_TILE = OS_TILE / 4;
-    __shared__ uint32_t cnt[4][256];
+    unsigned long long* gagg /*[groups][256], this pass's*/, uint32_t* tile_counter, uint32_t epoch, uint32_t* err) {
+    constexpr int NW = OS_THREADS / 64, NG = OS_THREADS / 256;
+    constexpr int OS_TILE = OS_THREADS * OS_ITEMS, OS_WAVE_TILE = OS_TILE / NW;
+    __shared__ uint32_t cnt[NW][256];
     __shared__ uint32_t delta[256];
     __shared__ uint32_t skey[OS_TILE], sval[OS_TILE];
-    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds_nw[NW];
     __shared__ uint32_t s_tile;
+    __shared__ uint32_t lb_part[NG][256];             // look-back: the thread groups' partial sums
     uint32_t n = live_count(n_ptr, cap);
     if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
 #pragma unroll
-    for (int i = 0; i < 4; i++) cnt[i][threadIdx.x] = 0;
+    for (int i = 0; i < NW * 256 / OS_THREADS; i++) (&cnt[0][0])[i * OS_THREADS + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     uint32_t block_base = tile * OS_TILE;
     if (block_base >= n) return;                      // later tiles are empty too: nobody waits on this one
+    OS_STAMP(0);
     int w = threadIdx.x >> 6, lane = lane_id();
     uint32_t wbase = block_base + w * OS_WAVE_TILE;
     uint32_t key[OS_ITEMS], val[OS_ITEMS], loc[OS_ITEMS];
@@ -472,80 +529,134 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_kernel(
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
     }
-    const uint32_t my_ghist = ghist_pass[threadIdx.x];
+    const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const uint32_t my_ghist = g == 0 ? ghist_pass[d] : 0u;
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n && !(DROP && key[r] == 0xFFFFFFFFu);
         uint32_t k = key[r];
-        uint32_t d = (k >> shift) & mask;
+        uint32_t dg = (k >> shift) & mask;
         unsigned long long peers = wave_ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            bool bit = (d >> b) & 1u;
+            bool bit = (dg >> b) & 1u;
             unsigned long long m = wave_ballot(bit);
             peers &= bit ? m : ~m;
         }
         uint32_t rank = __popcll(peers & lt_mask);
         uint32_t npeers = __popcll(peers);
-        uint32_t pre = valid ? cnt[w][d] : 0;
-        if (valid && rank == npeers - 1) cnt[w][d] = pre + npeers;
+        uint32_t pre = valid ? cnt[w][dg] : 0;
+        if (valid && rank == npeers - 1) cnt[w][dg] = pre + npeers;
         loc[r] = pre + rank;
     }
+    OS_STAMP(1);
     __syncthreads();
+    OS_STAMP(2);
     uint32_t tot;
     {
-        // thread d owns digit d: publish the tile's count, look back, publish the inclusive prefix
-        const uint32_t d = threadIdx.x;
-        uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-        uint32_t mine = c0 + c1 + c2 + c3;
-        unsigned long long* my_status = status + (size_t)tile * 256 + d;
-        __hip_atomic_store(my_status, os_pack(epoch, tile == 0 ? 2u : 1u, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (tile > 0) {
-            uint32_t p = tile - 1;
-            while (true) {
-                const unsigned long long* ps = status + (size_t)p * 256 + d;
-                unsigned long long wv;
-                unsigned spins = 0;
-                while (true) {
-                    wv = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(wv >> 34) == epoch && ((wv >> 32) & 3ull) != 0ull) break;
-                    if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 1u); wv = os_pack(epoch, 2u, 0u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                excl += (uint32_t)wv;
-                if (((wv >> 32) & 3ull) == 2ull || p == 0) break;
-                p--;
-            }
-            __hip_atomic_store(my_status, os_pack(epoch, 2u, excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // thread d of the first 256 owns digit d: publish the tile's count, look back, publish the inclusive prefix
+        uint32_t mine = 0;
+        // Look-back in ONE round trip.  Tiles form groups of OS_GRP; a tile publishes its count in status[tile][digit] and
+        // adds {1 << 40 | count} to its group's word gagg[group][digit].  Its exclusive prefix is the sum of the counts of
+        // the tiles before it in its own group (<= OS_GRP - 1 entries) and of the words of the groups before (complete
+        // once OS_GRP tiles have arrived): at most 15 + tiles/16 loads whose addresses are all known up front, spread
+        // over the NG thread groups and issued OS_LB at a time.  (The decoupled look-back this replaces -- aggregate /
+        // inclusive flags, walking back until an inclusive entry -- cost 4-7 us per pass with 163 tiles resident at once:
+        // an agent-scope load of another XCD's word takes ~0.5 us and a late tile needed several dependent windows.)
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) mine += cnt[i][d];
+            __hip_atomic_store(status + (size_t)tile * 256 + d, os_pack(epoch, 1u, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(gagg + (size_t)(tile / OS_GRP) * 256 + d, (1ull << 40) | (unsigned long long)mine,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        uint32_t excl = 0;
+        OS_STAMP(3);
+        if (tile > 0 && !(epoch & 0x40000000u)) {          // (bit 30 of the epoch: timing experiment, no look-back)
+            const int in_grp = (int)(tile % OS_GRP), n_grp = (int)(tile / OS_GRP), E = in_grp + n_grp;
+            const uint32_t ep = epoch & 0x3FFFFFFFu;
+            uint32_t part = 0;
+            for (int e0 = g; e0 < E; e0 += NG * OS_LB) {
+                unsigned long long wv[OS_LB];
+#pragma unroll
+                for (int i = 0; i < OS_LB; i++) {
+                    const int e = e0 + i * NG;
+                    const unsigned long long* a = e < in_grp ? status + (size_t)(tile - 1 - e) * 256 + d
+                                                             : gagg + (size_t)(e - in_grp) * 256 + d;
+                    wv[i] = e < E ? __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int i = 0; i < OS_LB; i++) {
+                    const int e = e0 + i * NG;
+                    if (e >= E) continue;
+                    const bool is_tile = e < in_grp;
+                    const unsigned long long* a = is_tile ? status + (size_t)(tile - 1 - e) * 256 + d
+                                                          : gagg + (size_t)(e - in_grp) * 256 + d;
+                    unsigned long long v = wv[i];
+                    unsigned spins = 0;
+                    while (is_tile ? !((uint32_t)(v >> 34) == ep && ((v >> 32) & 3ull) != 0ull) : (v >> 40) != (unsigned long long)OS_GRP) {
+                        if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 1u); v = 0ull; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    part += (uint32_t)v;
+                }
+            }
+            if (NG == 1) {
+                excl = part;
+            } else {
+                lb_part[g][d] = part;
+                __syncthreads();
+                if (g == 0) {
+#pragma unroll
+                    for (int gg = 0; gg < NG; gg++) excl += lb_part[gg][d];
+                }
+            }
+        }
+        OS_STAMP(4);
         // digit base = exclusive scan of the global histogram; local start = exclusive scan of this tile's counts
         uint32_t t2;
-        uint32_t dbase = block_excl_scan_u32(my_ghist, &t2, lds4);
-        uint32_t lstart = block_excl_scan_u32(mine, &tot, lds4);
-        cnt[0][d] = lstart; cnt[1][d] = lstart + c0; cnt[2][d] = lstart + c0 + c1; cnt[3][d] = lstart + c0 + c1 + c2;
-        delta[d] = dbase + excl - lstart;                                 // global = local slot + delta[digit]
+        uint32_t dbase = block_excl_scan_nw<NW>(my_ghist, &t2, lds_nw);
+        uint32_t lstart = block_excl_scan_nw<NW>(mine, &tot, lds_nw);
+        if (g == 0) {
+            uint32_t run = lstart;
+#pragma unroll
+            for (int i = 0; i < NW; i++) { const uint32_t ci = cnt[i][d]; cnt[i][d] = run; run += ci; }
+            delta[d] = dbase + excl - lstart;                             // global = local slot + delta[digit]
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         if (idx < n && !(DROP && key[r] == 0xFFFFFFFFu)) {
-            uint32_t d = (key[r] >> shift) & mask;
-            uint32_t slot = cnt[w][d] + loc[r];
+            uint32_t dg = (key[r] >> shift) & mask;
+            uint32_t slot = cnt[w][dg] + loc[r];
             skey[slot] = key[r];
             sval[slot] = val[r];
         }
     }
+    OS_STAMP(5);
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < tot; j += RS_THREADS) {
+    for (uint32_t j = threadIdx.x; j < tot; j += OS_THREADS) {
         uint32_t k = skey[j];
         uint32_t pos = j + delta[(k >> shift) & mask];
         keys_out[pos] = k;
         vals_out[pos] = sval[j];
     }
+    OS_STAMP(6);
+#ifdef MI3DGS_OS_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    OS_STAMP(7);
+#endif
 }
+
+#ifdef MI3DGS_OS_STAMPS
+extern "C" int mi3dgs_debug_read_os_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_os_stamps), bytes < sizeof(g_os_stamps) ? bytes : sizeof(g_os_stamps));
+}
+#endif
 
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 
@@ -567,13 +678,13 @@ size_t rs_tmp_u32(uint32_t cap) {
     uint32_t B = mi_div_up(cap, RS_TILE);
     size_t hist = (size_t)256 * B;
     size_t classic = hist + scan_tmp_u32(hist);
-    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + 2 * (size_t)256 * os_tiles_for(cap) + 16;
+    size_t onesweep = os_ctl_u32(cap) + 16;
     return classic > onesweep ? classic : onesweep;
 }
 
 size_t rs_zero_u32(uint32_t cap, int nbits) {
     const int passes = (nbits + 7) / 8;
-    size_t onesweep = (size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * os_tiles_for(cap);
+    size_t onesweep = os_ctl_u32(cap);
     size_t classic = (size_t)passes * align_u32(scan_tmp_u32((size_t)256 * mi_div_up(cap, RS_TILE)));
     return align_u32(onesweep > classic ? onesweep : classic);
 }
@@ -615,29 +726,41 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         MI_REQUIRE(err, "sort: no device error word");
         unsigned long long* status = reinterpret_cast<unsigned long long*>(ctl + OS_MAX_PASSES * 256 + 16);
         // one clear per sort call: histograms, counters, and the status table (epochs 1..passes)
-        if (!zeroed) MI_HIP(hipMemsetAsync(tmp, 0, ((size_t)OS_MAX_PASSES * 256 + 16 + (size_t)512 * B) * sizeof(uint32_t), st));
+        if (!zeroed) MI_HIP(hipMemsetAsync(tmp, 0, os_ctl_u32(cap) * sizeof(uint32_t), st));
+        unsigned long long* gagg = status + (size_t)256 * B;
+        const size_t gagg_pass = (size_t)256 * ((B + OS_GRP - 1) / OS_GRP);
         if (n_live_out) {
             MI_REQUIRE(!n_ptr, "sort: sentinel dropping needs a host-known input size");
             if (!zeroed) MI_HIP(hipMemsetAsync(n_live_out, 0, sizeof(uint32_t), st));
             if (small) MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            else if (os_big_items() == 16) MI_LAUNCH(htag, (os_hist_kernel<true, 16>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         } else {
             if (small) MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
+            else if (os_big_items() == 16) MI_LAUNCH(htag, (os_hist_kernel<false, 16>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         }
+        static const bool wide = [] { const char* e = getenv("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
-            if (n_live_out && p == 0)
-                { if (small) MI_LAUNCH(ctag, (os_pass_kernel<true, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
-                          ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
-                  else MI_LAUNCH(ctag, (os_pass_kernel<true, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, identity_vals ? nullptr : vi, ko, vo, n_ptr, cap, shift, mask,
-                          ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err); }
-            else
-                { if (small) MI_LAUNCH(ctag, (os_pass_kernel<false, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
-                          n_live_out ? n_live_out : n_ptr, cap, shift, mask, ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err);
-                  else MI_LAUNCH(ctag, (os_pass_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo,
-                          n_live_out ? n_live_out : n_ptr, cap, shift, mask, ghist + p * 256, status, counters + p, (uint32_t)(p + 1), err); }
+            const bool drop = n_live_out && p == 0;
+            const uint32_t* vin = (p == 0 && identity_vals) ? nullptr : vi;
+            const uint32_t* np = drop ? n_ptr : (n_live_out ? n_live_out : n_ptr);
+            const uint32_t ep = (uint32_t)(p + 1) | os_nolookback();
+#define OS_PASS(DROP_, T_, I_) MI_LAUNCH(ctag, (os_pass_kernel<DROP_, T_, I_>), dim3(B), dim3(T_), 0, st, ki, vin, ko, vo, np, cap, shift, mask, \
+                                         ghist + p * 256, status, gagg + p * gagg_pass, counters + p, ep, err)
+            // the same tile (2048 / 8192 keys) either way: 1024 threads x 2 / 8 items, or (A/B) 256 threads x 8 / 32
+            if (wide) {
+                const bool half = !small && os_big_items() == 16;
+                if (drop) { if (small) OS_PASS(true, 1024, OS_ITEMS_SMALL / 4); else if (half) OS_PASS(true, 1024, 4); else OS_PASS(true, 1024, OS_ITEMS_BIG / 4); }
+                else { if (small) OS_PASS(false, 1024, OS_ITEMS_SMALL / 4); else if (half) OS_PASS(false, 1024, 4); else OS_PASS(false, 1024, OS_ITEMS_BIG / 4); }
+            } else {
+                MI_REQUIRE(os_big_items() == OS_ITEMS_BIG, "sort: MI3DGS_OS_THREADS=256 goes with the default tile");
+                if (drop) { if (small) OS_PASS(true, 256, OS_ITEMS_SMALL); else OS_PASS(true, 256, OS_ITEMS_BIG); }
+                else { if (small) OS_PASS(false, 256, OS_ITEMS_SMALL); else OS_PASS(false, 256, OS_ITEMS_BIG); }
+            }
+#undef OS_PASS
             uint32_t* t;
             t = ki; ki = ko; ko = t;
             t = vi; vi = vo; vo = t;
