@@ -261,6 +261,26 @@ __device__ __forceinline__ uint32_t live_count(const uint32_t* n_ptr, uint32_t c
     return n < cap ? n : cap;
 }
 
+// Match-any over the wave on the low BITS bits of `digit`: *npeers = lanes holding the same digit (valid lanes only),
+// *rank = those among them below this lane.  Per bit: one sign-extending bit-field extract, one compare (the ballot) and
+// one three-input bit operation per 32-lane half (peers &= ~(ballot ^ sext(bit))) -- written out on halves because the
+// 64-bit "bit ? m : ~m" form compiled to ten VALU instructions per bit, and these kernels are VALU bound on this loop.
+template <int BITS>
+__device__ __forceinline__ void match_rank(uint32_t digit, bool valid, uint32_t lt_lo, uint32_t lt_hi, uint32_t* rank,
+                                           uint32_t* npeers) {
+    const unsigned long long vm = wave_ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const uint32_t sx = (uint32_t)((int32_t)(digit << (31 - b)) >> 31);          // all ones where the bit is set
+        const unsigned long long m = wave_ballot(sx != 0u);
+        plo &= ~((uint32_t)m ^ sx);
+        phi &= ~((uint32_t)(m >> 32) ^ sx);
+    }
+    *rank = __popc(plo & lt_lo) + __popc(phi & lt_hi);
+    *npeers = __popc(plo) + __popc(phi);
+}
+
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                              int shift, uint32_t mask, uint32_t* __restrict__ hist,
@@ -344,15 +364,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
         uint32_t d = (key[r] >> shift) & mask;
-        unsigned long long peers = wave_ballot(valid);
-#pragma unroll
-        for (int b = 0; b < BITS; b++) {
-            bool bit = (d >> b) & 1u;
-            unsigned long long m = wave_ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t rank = __popcll(peers & lt_mask);
-        uint32_t npeers = __popcll(peers);
+        uint32_t rank, npeers;
+        match_rank<BITS>(d, valid, (uint32_t)lt_mask, (uint32_t)(lt_mask >> 32), &rank, &npeers);
         uint32_t pre = valid ? cnt[w][d] : 0;
         if (valid && rank == npeers - 1) cnt[w][d] = pre + npeers;
         loc[r] = pre + rank;
@@ -537,15 +550,8 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
         bool valid = idx < n && !(DROP && key[r] == 0xFFFFFFFFu);
         uint32_t k = key[r];
         uint32_t dg = (k >> shift) & mask;
-        unsigned long long peers = wave_ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            bool bit = (dg >> b) & 1u;
-            unsigned long long m = wave_ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t rank = __popcll(peers & lt_mask);
-        uint32_t npeers = __popcll(peers);
+        uint32_t rank, npeers;
+        match_rank<8>(dg, valid, (uint32_t)lt_mask, (uint32_t)(lt_mask >> 32), &rank, &npeers);
         uint32_t pre = valid ? cnt[w][dg] : 0;
         if (valid && rank == npeers - 1) cnt[w][dg] = pre + npeers;
         loc[r] = pre + rank;
@@ -665,7 +671,10 @@ __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 // 216 -> 178 us) and loses on large sorts (15 M keys, 2 passes: 350 -> 429 us; the look-back
 // chains are dependent sc1 loads served by L2, several hundred cycles each).
 int g_sort_mode = 2;
-constexpr uint32_t OS_MAX_KEYS = 4u << 20;
+inline uint32_t os_max_keys() {                       // (MI3DGS_OS_MAX_KEYS: A/B of the switch-over to the classic passes)
+    static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_MAX_KEYS"); return e ? (uint32_t)atol(e) : (4u << 20); }();
+    return v;
+}
 
 inline size_t align_u32(size_t n) { return (n + 63) & ~(size_t)63; }
 
@@ -715,7 +724,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     int per = (nbits + passes - 1) / passes;
     int shift = 0;
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
-    if (g_sort_mode == 1 || (g_sort_mode == 2 && cap <= OS_MAX_KEYS)) {
+    if (g_sort_mode == 1 || (g_sort_mode == 2 && cap <= os_max_keys())) {
         const uint32_t B = os_tiles_for(cap);          // (shadows the classic tile count)
         const bool small = os_items_for(cap) == OS_ITEMS_SMALL;
         // layout: ghist[4][256] | counters[8] err[1] pad[7] | status[B][256] u64
