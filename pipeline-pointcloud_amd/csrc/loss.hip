@@ -24,6 +24,7 @@ constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 constexpr int NT = 512;            // threads per block: LDS allows 2 blocks/CU, so waves come from block size
 constexpr int VO = LT * LT / NT;   // output rows per thread in the vertical pass
+constexpr int NM = 4;              // blurred moments of the forward: u, v, u^2 + v^2, u v
 constexpr int ROW3 = LW * 3;       // floats of one staged image row in memory (interleaved RGB)
 
 __constant__ float GW[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
@@ -90,7 +91,7 @@ __device__ __forceinline__ void stage_store(float (*plane)[LW][LS], const StageC
 
 // Forward.  One 256-thread block per 32x32 output tile and camera.  Per channel:
 //   horizontal pass: task (row r of 42, group of 4 columns) slides an 11-tap window over 14
-//     staged values -> 4 outputs x 5 moments (u, v, uu, vv, uv), written to hz[5][42][32];
+//     staged values -> 4 outputs x 4 moments (u, v, uu + vv, uv), written to hz[4][42][32];
 //   vertical pass: thread (column, group of 4 rows) slides over 14 rows of hz -> 4 pixels.
 // The first version (16x16 tiles, one output per thread, 55 LDS reads per pixel-channel in
 // the vertical pass, 2-way bank conflicts on half its LDS cycles) took 232 us; the halo
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
                                                        float* __restrict__ dm_dsig1, float* __restrict__ dm_dsig12,
                                                        float* __restrict__ sums /* [0]=L1 sum, [1]=SSIM sum */) {
     __shared__ float pu[3][LW][LS], pv[3][LW][LS];
-    __shared__ float hz[5][LW][HS];
+    __shared__ float hz[NM][LW][HS];
     __shared__ float red[NT / 64];
     const int cam = blockIdx.z;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -119,42 +120,42 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
     for (int ch = 0; ch < 3; ch++) {
         for (int t = threadIdx.x; t < LW * (LT / 4); t += NT) {
             int r = t >> 3, c0 = (t & 7) * 4;
-            float u[14], v[14], uu[14], vv[14], uv[14];
+            float u[14], v[14], sq[14], uv[14];
 #pragma unroll
             for (int k = 0; k < 14; k++) { u[k] = pu[ch][r][c0 + k]; v[k] = pv[ch][r][c0 + k]; }
-            // the three products once per staged value (42 multiplies), not once per (output, tap) pair (88 + 44)
+            // the products once per staged value, not once per (output, tap) pair; SSIM and its three derivative maps only
+            // ever use sigma1^2 + sigma2^2, so u^2 + v^2 is blurred as ONE plane (four moments instead of five)
 #pragma unroll
-            for (int k = 0; k < 14; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
+            for (int k = 0; k < 14; k++) { sq[k] = __builtin_fmaf(u[k], u[k], v[k] * v[k]); uv[k] = u[k] * v[k]; }
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+                float s1 = 0.f, s2 = 0.f, ssq = 0.f, s12 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
                     const float w = GW[k];
-                    s1 += w * u[o + k]; s2 += w * v[o + k]; s11 += w * uu[o + k]; s22 += w * vv[o + k]; s12 += w * uv[o + k];
+                    s1 += w * u[o + k]; s2 += w * v[o + k]; ssq += w * sq[o + k]; s12 += w * uv[o + k];
                 }
-                hz[0][r][c0 + o] = s1; hz[1][r][c0 + o] = s2; hz[2][r][c0 + o] = s11; hz[3][r][c0 + o] = s22;
-                hz[4][r][c0 + o] = s12;
+                hz[0][r][c0 + o] = s1; hz[1][r][c0 + o] = s2; hz[2][r][c0 + o] = ssq; hz[3][r][c0 + o] = s12;
             }
         }
         __syncthreads();
         {
-            float acc[VO][5];
+            float acc[VO][NM];
 #pragma unroll
             for (int o = 0; o < VO; o++)
 #pragma unroll
-                for (int q = 0; q < 5; q++) acc[o][q] = 0.f;
+                for (int q = 0; q < NM; q++) acc[o][q] = 0.f;
 #pragma unroll
             for (int k = 0; k < VO + 10; k++) {
-                float h[5];
+                float h[NM];
 #pragma unroll
-                for (int q = 0; q < 5; q++) h[q] = hz[q][vg * VO + k][vc];
+                for (int q = 0; q < NM; q++) h[q] = hz[q][vg * VO + k][vc];
 #pragma unroll
                 for (int o = 0; o < VO; o++) {
                     int tap = k - o;
                     if (tap >= 0 && tap < 11) {
 #pragma unroll
-                        for (int q = 0; q < 5; q++) acc[o][q] += GW[tap] * h[q];
+                        for (int q = 0; q < NM; q++) acc[o][q] += GW[tap] * h[q];
                     }
                 }
             }
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
                 if (px < W && py < H) {
                     float mu1 = acc[o][0], mu2 = acc[o][1];
                     float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                    float sg1 = acc[o][2] - mu1s, sg2 = acc[o][3] - mu2s, sg12 = acc[o][4] - mu12;
-                    float A = mu1s + mu2s + C1, B = sg1 + sg2 + C2, Cc = 2.f * mu12 + C1, D = 2.f * sg12 + C2;
+                    float sg_sum = (acc[o][2] - mu1s) - mu2s, sg12 = acc[o][3] - mu12;      // sigma1^2 + sigma2^2, sigma12
+                    float A = mu1s + mu2s + C1, B = sg_sum + C2, Cc = 2.f * mu12 + C1, D = 2.f * sg12 + C2;
                     float rAB = 1.f / (A * B);
                     ss += Cc * D * rAB;
                     float a = pu[ch][vg * VO + o + HALO][vc + HALO], b = pv[ch][vg * VO + o + HALO][vc + HALO];
