@@ -199,10 +199,34 @@ __device__ __forceinline__ void sh_basis_vjp(int deg, float x, float y, float z,
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
 constexpr int SH_WAVE_F4 = 64 * 45 / 4;   // one wave's shN slice in float4 units (11 520 B)
+constexpr int SH_HALF_F4 = 32 * 45 / 4;   // 32 rows of it (5 760 B)
+
+// colour += sum over the bases 1 .. nb - 1 of b[k] * coefficient row k (45 floats in LDS).  All 45 LDS reads go out together:
+// a loop over the runtime degree waits out one LDS round trip per coefficient.
+__device__ __forceinline__ void sh_accumulate(const float* cN, const float (&b)[16], int nb, float (&rgb)[3]) {
+    // five bases (15 floats) per LDS round trip: one at a time a loop over the runtime degree waits out 15 round trips, all 45
+    // at once cost 45 live registers on top of the slice half still waiting in registers
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        float cf[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) cf[k] = cN[15 * g + k];
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+            const int k = 1 + 5 * g + kk;
+            const float bk = k < nb ? b[k] : 0.f;
+            rgb[0] += bk * (k < nb ? cf[3 * kk] : 0.f);
+            rgb[1] += bk * (k < nb ? cf[3 * kk + 1] : 0.f);
+            rgb[2] += bk * (k < nb ? cf[3 * kk + 2] : 0.f);
+        }
+    }
+}
 
 // --------------------------------------------------------------------------- forward
 // color_mode: 0 = SH (sh0[N,3] + shN[N,15,3]), 1 = colors[N,3], 2 = colors[C,N,3]
-__global__ __launch_bounds__(256) void project_fwd_kernel(
+// (waves_per_eu: with 23 KB of LDS the compiler otherwise aims at six waves per SIMD and gets there by parking the staged
+// slice in scratch, one waited load at a time)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void project_fwd_kernel(
     int C, int N, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities,
     const float* __restrict__ sh0, const float* __restrict__ shN, const float* __restrict__ colors,
@@ -214,7 +238,12 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     // (62 VMEM instructions per wave); instead the wave copies the slice with 16-byte loads
     // into LDS and every lane reads its 45 coefficients from there (stride 45 dwords: odd,
     // bank-conflict free).
-    __shared__ float4 sSH4[4][SH_WAVE_F4];
+    // The slice goes through LDS in two halves of 32 rows (5 760 B per wave instead of 11 520: four waves per SIMD instead
+    // of three); the second half's loads are in flight while the lanes of the first evaluate.  Measured 150 -> 145 us on one
+    // box: the kernel is bound by its ~2 000 vector instructions per wave more than by latency (padding the LDS back to three
+    // blocks per CU costs 2 us), and fetching only the rows of visible Gaussians is worth more than the index arithmetic it
+    // costs (146 against 155 us without).
+    __shared__ float4 sSH4[4][SH_HALF_F4];
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const bool live = idx < (long long)C * N;
@@ -268,6 +297,19 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float c0[3] = {0.f, 0.f, 0.f};
     if (color_mode == 0 && ok) { c0[0] = sh0[3 * (long long)n]; c0[1] = sh0[3 * (long long)n + 1]; c0[2] = sh0[3 * (long long)n + 2]; }
     bool staged = false;
+    float staged_rgb[3] = {0.f, 0.f, 0.f};          // the shN part of the colour when the slice went through LDS
+    float b[16];                                    // SH basis of the view direction (zeros for a culled lane)
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.f;
+    if (color_mode == 0 && ok) {
+        // campos = -R^T t ; dir = mean - campos
+        float cp[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) cp[i] = -(cam.R[i] * cam.t[0] + cam.R[3 + i] * cam.t[1] + cam.R[6 + i] * cam.t[2]);
+        float dx = mean[0] - cp[0], dy = mean[1] - cp[1], dz = mean[2] - cp[2];
+        float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
+        sh_basis(sh_degree, dx * inv, dy * inv, dz * inv, b);
+    }
     if (color_mode == 0 && sh_degree >= 2) {
         long long idx0 = idx - lane;                                  // first record of the wave
         int n0 = (int)(idx0 - (long long)(idx0 / N) * N);
@@ -282,19 +324,41 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             // Only the rows of Gaussians that survived the culling are fetched (a third of them did not in the 2 M scene:
             // 120 MB of 625): a float4 none of whose rows is needed reads the slice's first 16 bytes instead (one address for
             // all such lanes, no branch).
-            float4 tmp[(SH_WAVE_F4 + 63) / 64];
-#pragma unroll
-            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
-                const int i4 = min(lane + 64 * j, SH_WAVE_F4 - 1);
+            constexpr int HJ = (SH_HALF_F4 + 63) / 64;               // 6 loads per lane and half
+            // (two plain arrays and straight-line code: as tmp[2][HJ] under a loop over the halves the compiler put the
+            // values in scratch and waited for every load on its own)
+            const int nb = (sh_degree + 1) * (sh_degree + 1);
+            static_assert(HJ == 6, "six named registers per half below");
+            // (named values, not an array: an array that is live across the wavefront fences stays a stack object -- the
+            // compiler stored all of it to scratch at every fence)
+            float4 u0, u1, u2, u3, u4, u5;
+            auto fetch = [&](int j, unsigned okw, int ofs) -> float4 {
+                const int i4 = min(lane + 64 * j, SH_HALF_F4 - 1);
                 const int r0 = (4 * i4) / 45, r1 = (4 * i4 + 3) / 45;
-                const bool need = ((okm >> r0) | (okm >> r1)) & 1ull;
-                tmp[j] = s4[need ? i4 : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
-                int i4 = lane + 64 * j;
-                if (i4 < SH_WAVE_F4) sSH4[wv][i4] = tmp[j];
-            }
+                const bool need = ((okw >> r0) | (okw >> r1)) & 1u;
+                return s4[need ? ofs + i4 : 0];
+            };
+            auto put = [&](int j, const float4& v) {
+                const int i4 = lane + 64 * j;
+                if (i4 < SH_HALF_F4) sSH4[wv][i4] = v;
+            };
+            const unsigned okl = (unsigned)okm, okh = (unsigned)(okm >> 32);
+            u0 = fetch(0, okl, 0); u1 = fetch(1, okl, 0); u2 = fetch(2, okl, 0);
+            u3 = fetch(3, okl, 0); u4 = fetch(4, okl, 0); u5 = fetch(5, okl, 0);
+            put(0, u0); put(1, u1); put(2, u2); put(3, u3); put(4, u4); put(5, u5);
+            // the second half is requested before the first is evaluated (the wavefront-scope fences order the LDS traffic of
+            // this wave without waiting for the loads in flight)
+            u0 = fetch(0, okh, SH_HALF_F4); u1 = fetch(1, okh, SH_HALF_F4); u2 = fetch(2, okh, SH_HALF_F4);
+            u3 = fetch(3, okh, SH_HALF_F4); u4 = fetch(4, okh, SH_HALF_F4); u5 = fetch(5, okh, SH_HALF_F4);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");            // same-wave LDS hand-off: order only
+            __builtin_amdgcn_wave_barrier();
+            if (ok && lane < 32) sh_accumulate(reinterpret_cast<const float*>(sSH4[wv]) + 45 * lane, b, nb, staged_rgb);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");            // the first half has been read
+            __builtin_amdgcn_wave_barrier();
+            put(0, u0); put(1, u1); put(2, u2); put(3, u3); put(4, u4); put(5, u5);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (ok && lane >= 32) sh_accumulate(reinterpret_cast<const float*>(sSH4[wv]) + 45 * (lane - 32), b, nb, staged_rgb);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");            // same-wave LDS hand-off: order only
@@ -308,23 +372,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     }
     float rgb[3];
     if (color_mode == 0) {
-        // campos = -R^T t ; dir = mean - campos
-        float cp[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) cp[i] = -(cam.R[i] * cam.t[0] + cam.R[3 + i] * cam.t[1] + cam.R[6 + i] * cam.t[2]);
-        float dx = mean[0] - cp[0], dy = mean[1] - cp[1], dz = mean[2] - cp[2];
-        float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f));
-        float b[16];
-        sh_basis(sh_degree, dx * inv, dy * inv, dz * inv, b);
         rgb[0] = b[0] * c0[0]; rgb[1] = b[0] * c0[1]; rgb[2] = b[0] * c0[2];
         int nb = (sh_degree + 1) * (sh_degree + 1);
         if (staged) {
-            const float* cN = reinterpret_cast<const float*>(sSH4[wv]) + 45 * lane;
-            for (int k = 1; k < nb; k++) {
-                rgb[0] += b[k] * cN[3 * (k - 1)];
-                rgb[1] += b[k] * cN[3 * (k - 1) + 1];
-                rgb[2] += b[k] * cN[3 * (k - 1) + 2];
-            }
+            rgb[0] += staged_rgb[0]; rgb[1] += staged_rgb[1]; rgb[2] += staged_rgb[2];
         } else {
             const float* cN = shN + 45 * (long long)n;
             for (int k = 1; k < nb; k++) {
