@@ -333,14 +333,19 @@ def main():
             # ALGORITHMIC bytes per launch (BASELINE.md section 3 / DESIGN.md "Kernels"):
             # I intersections, n Gaussians, n_vis visible, Px pixels
             I = n_isect
+            # bytes of a tile key: 2 when the library sorts 16-bit keys (the step does not read the keys back, every tile id
+            # fits, and the sort is above the switch-over to the classic passes; MI3DGS_KEYS16=0 turns it off)
+            tiles = ((sc.width + 15) // 16) * ((sc.height + 15) // 16)
+            kb = 2 if (tiles <= 65536 and (tr.cfg.max_isect or 0) > (4 << 20) and not args.two_phase_binning
+                       and os.environ.get("MI3DGS_KEYS16", "1") != "0") else 4
             alg = {
                 "project_fwd": n * 44 + n_vis * (192 + 72),
                 "tile_count": n * 8 + n_vis * 16 + n * 12,
                 "rs_hist/depth": n * 4, "rs_scatter/depth": n * 16,
                 "gather_tiles": n * 12,
-                "tile_emit": n * 8 + n_vis * 24 + I * 8,
-                "rs_hist/isect": I * 4, "rs_scatter/isect": I * 16,
-                "tile_offsets": I * 4,
+                "tile_emit": n * 8 + n_vis * 24 + I * (4 + kb),
+                "rs_hist/isect": I * kb, "rs_scatter/isect": I * (8 + 2 * kb),
+                "tile_offsets": I * kb,
                 "rasterize_fwd": I * 40 + Px * 20,
                 "loss_fwd": Px * (24 + 36), "loss_bwd": Px * (60 + 12),
                 "rasterize_bwd": I * 80 + Px * 32,

@@ -119,7 +119,10 @@ size_t mi3dgs_bin_workspace_bytes(int C, int N, long long max_isect);
  * shorter.  `height` is the image height in pixels.  Both phases must use the same value.
  * `tight` is a bit field: bit 0 as above; bit 1 (value 2) = the splat records carry their integer radii in
  * slots 11 and 12 (mi3dgs_project_fwd writes them there), so the emit pass gathers ONE line per splat instead of
- * a record plus an 8-byte radii entry from a second random sector.  Leave it clear for hand-made records. */
+ * a record plus an 8-byte radii entry from a second random sector.  Leave it clear for hand-made records.
+ * Bit 2 (value 4, mi3dgs_bin_tiles only) = the caller does not read `tile_keys` back: the buffer (still max_isect words)
+ * is scratch and its contents are unspecified on return.  The library then sorts 16-bit tile keys whenever every tile id
+ * fits and isect_ids_opt is null; flatten_ids and isect_offsets are the same bit for bit. */
 int mi3dgs_bin_count(int C, int N, const int32_t* radii, const float* splats, int tile_size,
                      int tile_width, int tile_height, int height, int tight,
                      int32_t* tiles_per_gauss /* [C*N], nullable */, int32_t* n_isect_dev /* [1] */,

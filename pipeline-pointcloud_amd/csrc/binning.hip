@@ -281,7 +281,10 @@ __device__ __forceinline__ void match_rank(uint32_t digit, bool valid, uint32_t 
     *npeers = __popc(plo) + __popc(phi);
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys,
+// KT = key type: uint32_t, or uint16_t for the tile sort when every tile id fits 16 bits (the pairs then move 6 bytes
+// per pass instead of 8)
+template <typename KT>
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const KT* __restrict__ keys,
                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                              int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                              uint32_t B) {
@@ -298,10 +301,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
         uint32_t k[RS_ITEMS];
         if (first + RS_ITEMS <= n) {
             const uint4* k4 = reinterpret_cast<const uint4*>(keys + first);
+            if (sizeof(KT) == 4) {
 #pragma unroll
-            for (int i = 0; i < RS_ITEMS / 4; i++) {
-                uint4 v = k4[i];
-                k[4 * i] = v.x; k[4 * i + 1] = v.y; k[4 * i + 2] = v.z; k[4 * i + 3] = v.w;
+                for (int i = 0; i < RS_ITEMS / 4; i++) {
+                    uint4 v = k4[i];
+                    k[4 * i] = v.x; k[4 * i + 1] = v.y; k[4 * i + 2] = v.z; k[4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS / 8; i++) {
+                    uint4 v = k4[i];
+                    k[8 * i] = v.x & 0xFFFFu; k[8 * i + 1] = v.x >> 16; k[8 * i + 2] = v.y & 0xFFFFu; k[8 * i + 3] = v.y >> 16;
+                    k[8 * i + 4] = v.z & 0xFFFFu; k[8 * i + 5] = v.z >> 16; k[8 * i + 6] = v.w & 0xFFFFu; k[8 * i + 7] = v.w >> 16;
+                }
             }
         } else {
 #pragma unroll
@@ -329,14 +341,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
 
 // BITS = width of this pass's digit: the match-any ranking below costs one ballot + a 64-bit per-lane select per
 // digit bit and key, and the tile sort's passes are 7 and 6 bits wide, not 8 (the kernel is VALU bound on it)
-template <int BITS>
+template <int BITS, typename KT>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ hist_scanned, uint32_t B) {
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t delta[256];
-    __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
+    __shared__ KT skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
     __shared__ uint32_t lds4[4];
     uint32_t n = live_count(n_ptr, cap);
     uint32_t block_base = blockIdx.x * RS_TILE;
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int r = 0; r < RS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        key[r] = valid ? (uint32_t)keys_in[idx] : 0xFFFFFFFFu;
         val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
     }
     const uint32_t my_global = hist_scanned[threadIdx.x * B + blockIdx.x];     // digit = threadIdx.x
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         if (idx < n) {
             uint32_t d = (key[r] >> shift) & mask;
             uint32_t slot = cnt[w][d] + loc[r];
-            skey[slot] = key[r];
+            skey[slot] = (KT)key[r];
             sval[slot] = val[r];
         }
     }
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (uint32_t j = threadIdx.x; j < tot; j += RS_THREADS) {
         uint32_t k = skey[j];
         uint32_t pos = j + delta[(k >> shift) & mask];
-        keys_out[pos] = k;
+        keys_out[pos] = (KT)k;
         vals_out[pos] = sval[j];
     }
 }
@@ -698,6 +711,50 @@ size_t rs_zero_u32(uint32_t cap, int nbits) {
     return align_u32(onesweep > classic ? onesweep : classic);
 }
 
+// The classic passes (histogram, scan, scatter per digit) on keys of type KT.
+template <typename KT>
+int rs_classic(KT* keys_a, uint32_t* vals_a, KT* keys_b, uint32_t* vals_b, const uint32_t* n_ptr, uint32_t cap, int nbits,
+               uint32_t* tmp, int* result_in_b, hipStream_t st, const char* htag, const char* ctag, const char* s0,
+               bool identity_vals, uint32_t* zeroed) {
+    *result_in_b = 0;
+    if (cap == 0 || nbits <= 0) return 0;
+    const uint32_t B = mi_div_up(cap, RS_TILE);
+    const int passes = (nbits + 7) / 8;
+    const int per = (nbits + passes - 1) / passes;       // the bits spread evenly over the passes (13 bits -> 7 + 6)
+    int shift = 0;
+    KT *ki = keys_a, *ko = keys_b;
+    uint32_t *vi = vals_a, *vo = vals_b;
+    uint32_t* hist = tmp;
+    uint32_t* scan_tmp = tmp + (size_t)256 * B;
+    for (int p = 0; p < passes; p++) {
+        int bits = (shift + per <= nbits) ? per : (nbits - shift);
+        uint32_t mask = (1u << bits) - 1u;
+        MI_LAUNCH(htag, rs_hist_kernel<KT>, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
+        // (pre-cleared scan scratch: one region per pass)
+        // (digit-major histogram: the digits this pass does not have are zeros at its tail and need no scanning)
+        const uint32_t nscan = (mask + 1u) * B;
+        int rc = zeroed ? scan_exclusive_u32(hist, hist, nscan, zeroed + (size_t)p * align_u32(scan_tmp_u32((size_t)256 * B)), nullptr, st, s0, true)
+                        : scan_exclusive_u32(hist, hist, nscan, scan_tmp, nullptr, st, s0);
+        if (rc) return rc;
+#define RS_SCATTER(NB) MI_LAUNCH(ctag, (rs_scatter_kernel<NB, KT>), dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, \
+                                 n_ptr, cap, shift, mask, hist, B)
+        switch (bits) {
+            case 1: case 2: case 3: case 4: RS_SCATTER(4); break;
+            case 5: RS_SCATTER(5); break;
+            case 6: RS_SCATTER(6); break;
+            case 7: RS_SCATTER(7); break;
+            default: RS_SCATTER(8); break;
+        }
+#undef RS_SCATTER
+        MI_LAUNCH_CHECK();
+        KT* t = ki; ki = ko; ko = t;
+        uint32_t* tv = vi; vi = vo; vo = tv;
+        shift += bits;
+    }
+    *result_in_b = passes & 1;
+    return 0;
+}
+
 // LSD radix sort of (key,val) u32 pairs on bits [0, nbits).  Result ends up in (keys_a, vals_a)
 // if the number of passes is even, else in (keys_b, vals_b); returns via *result_in_b.
 int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr,
@@ -718,7 +775,6 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     const char* ctag = ctag_buf;
     *result_in_b = 0;
     if (cap == 0 || nbits <= 0) return 0;
-    uint32_t B = mi_div_up(cap, RS_TILE);
     int passes = (nbits + 7) / 8;
     // spread the bits evenly over the passes (13 bits -> 7 + 6)
     int per = (nbits + passes - 1) / passes;
@@ -780,36 +836,20 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         return 0;
     }
     if (n_live_out) MI_LAUNCH("set_u32", set_u32_kernel, dim3(1), dim3(1), 0, st, n_live_out, cap);
-    uint32_t* hist = tmp;
-    uint32_t* scan_tmp = tmp + (size_t)256 * B;
-    for (int p = 0; p < passes; p++) {
-        int bits = (shift + per <= nbits) ? per : (nbits - shift);
-        uint32_t mask = (1u << bits) - 1u;
-        MI_LAUNCH(htag, rs_hist_kernel, dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, shift, mask, hist, B);
-        // (pre-cleared scan scratch: one region per pass)
-        // (digit-major histogram: the digits this pass does not have are zeros at its tail and need no scanning)
-        const uint32_t nscan = (mask + 1u) * B;
-        int rc = zeroed ? scan_exclusive_u32(hist, hist, nscan, zeroed + (size_t)p * align_u32(scan_tmp_u32((size_t)256 * B)), nullptr, st, s0, true)
-                        : scan_exclusive_u32(hist, hist, nscan, scan_tmp, nullptr, st, s0);
-        if (rc) return rc;
-#define RS_SCATTER(NB) MI_LAUNCH(ctag, rs_scatter_kernel<NB>, dim3(B), dim3(RS_THREADS), 0, st, ki, (p == 0 && identity_vals) ? nullptr : vi, ko, vo, \
-                                 n_ptr, cap, shift, mask, hist, B)
-        switch (bits) {
-            case 1: case 2: case 3: case 4: RS_SCATTER(4); break;
-            case 5: RS_SCATTER(5); break;
-            case 6: RS_SCATTER(6); break;
-            case 7: RS_SCATTER(7); break;
-            default: RS_SCATTER(8); break;
-        }
-#undef RS_SCATTER
-        MI_LAUNCH_CHECK();
-        uint32_t* t;
-        t = ki; ki = ko; ko = t;
-        t = vi; vi = vo; vo = t;
-        shift += bits;
-    }
-    *result_in_b = passes & 1;
-    return 0;
+    return rs_classic<uint32_t>(keys_a, vals_a, keys_b, vals_b, n_ptr, cap, nbits, tmp, result_in_b, st, htag, ctag, s0,
+                                identity_vals, zeroed);
+}
+
+// The same for 16-bit keys (the tile sort when no tile id needs more): classic passes only.
+int radix_sort_pairs_k16(uint16_t* keys_a, uint32_t* vals_a, uint16_t* keys_b, uint32_t* vals_b, const uint32_t* n_ptr,
+                         uint32_t cap, int nbits, uint32_t* tmp, int* result_in_b, hipStream_t st, const char* what,
+                         uint32_t* zeroed) {
+    static thread_local char htag_buf[48], ctag_buf[48], s0[48];
+    snprintf(htag_buf, sizeof(htag_buf), "rs_hist/%s", what);
+    snprintf(ctag_buf, sizeof(ctag_buf), "rs_scatter/%s", what);
+    snprintf(s0, sizeof(s0), "scan/%s", what);
+    return rs_classic<uint16_t>(keys_a, vals_a, keys_b, vals_b, n_ptr, cap, nbits, tmp, result_in_b, st, htag_buf, ctag_buf, s0,
+                                false, zeroed);
 }
 
 // ------------------------------------------------------------------------ tile binning
@@ -1214,11 +1254,11 @@ inline int we_spw_for(uint32_t CN) {
 }
 inline size_t we_chain_entries(uint32_t CN) { return (size_t)WE_WAVES * (size_t)mi_div_up(CN, (long long)we_spw_for(CN) * WE_WAVES); }
 
-template <int SPW>
+template <int SPW, typename KT>
 __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
     uint32_t CN_cap, const uint32_t* __restrict__ n_sorted_ptr, bool radii_in_records, uint32_t N,
     const uint32_t* __restrict__ sorted_ids, const int32_t* __restrict__ radii, const float* __restrict__ splats, int tile_size,
-    int tw, int th, int H, uint32_t cap, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ flat_ids,
+    int tw, int th, int H, uint32_t cap, KT* __restrict__ tile_keys, uint32_t* __restrict__ flat_ids,
     unsigned long long* status, uint32_t* chain_counter, uint32_t* chain_err, uint32_t* __restrict__ n_isect_out,
     uint32_t* __restrict__ tiles_out) {
     __shared__ WaveEmitLds Lw[WE_WAVES];
@@ -1417,7 +1457,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
                 const uint32_t rank = before + (uint32_t)__popcll(m & le_mask) - 1u;     // slot 0 of the chunk starts an item: rank >= 0
                 const uint32_t p = base + running + q;
                 if (p < cap) {
-                    tile_keys[p] = L.it_key[rank] + (q - L.it_start[rank]);
+                    tile_keys[p] = (KT)(L.it_key[rank] + (q - L.it_start[rank]));
                     flat_ids[p] = L.it_id[rank];
                 }
             }
@@ -1493,7 +1533,8 @@ __global__ __launch_bounds__(256) void tile_emit_slow_kernel(const uint32_t* __r
 // offsets[t] = first sorted position whose key >= t   (t in [0, n_tiles_total)).  Four keys per thread
 // (one 16-byte load plus the key before them); a boundary between two different keys writes the
 // offsets of every tile id in between.
-__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ keys,
+template <typename KT>
+__global__ __launch_bounds__(256) void tile_offsets_kernel(const KT* __restrict__ keys,
                                                            const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                            uint32_t n_tiles_total, int32_t* __restrict__ offsets) {
     uint32_t n = live_count(n_ptr, cap);
@@ -1505,8 +1546,13 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
     if (i0 >= n) return;
     uint32_t k[4];
     if (i0 + 4 <= n) {
-        uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
-        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+        if (sizeof(KT) == 4) {
+            uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
+            k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+        } else {
+            uint2 q = *reinterpret_cast<const uint2*>(keys + i0);
+            k[0] = q.x & 0xFFFFu; k[1] = q.x >> 16; k[2] = q.y & 0xFFFFu; k[3] = q.y >> 16;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? keys[i0 + j] : 0u;
@@ -1651,7 +1697,7 @@ static int bin_sort_and_offsets(const BinWs& ws, uint32_t* tk, uint32_t* fi, con
         MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
     }
     uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
-    MI_LAUNCH("tile_offsets", tile_offsets_kernel, dim3(mi_div_up(mi_div_up(g, 4), 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
+    MI_LAUNCH("tile_offsets", tile_offsets_kernel<uint32_t>, dim3(mi_div_up(mi_div_up(g, 4), 256)), dim3(256), 0, st, tk, (const uint32_t*)n_isect_dev,
                        cap, n_tiles_total, isect_offsets);
     if (isect_ids_opt)
         MI_LAUNCH("isect_ids", isect_ids_kernel, dim3(mi_div_up(cap, 256)), dim3(256), 0, st, tk, fi,
@@ -1734,6 +1780,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
                   ws.ids_a);
     // the depth sort leaves the culled splats (key 0xFFFFFFFF) behind: everything after it walks the visible ones only
     const bool rir = (tight & MI_BIN_RADII_IN_RECORDS) != 0;
+    const bool keys_scratch = (tight & MI_BIN_KEYS_SCRATCH) != 0;
     tight &= MI_BIN_TIGHT;
     // every control word of this call (live count, chain state, both sorts' histograms / status tables / scan scratch) sits in
     // one block cleared by one memset: the call used to issue seven small clears at ~4.5 us of stream time each
@@ -1759,18 +1806,19 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     const bool wave_emit = tight && g_emit_mode == 1 && tile_width <= WE_GROUPS;
-    if (wave_emit && we_spw_for(CN) == 16)
-        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<16>, dim3(mi_div_up(CN, 16 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
-                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
-                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
-    else if (wave_emit && we_spw_for(CN) == 32)
-        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<32>, dim3(mi_div_up(CN, 32 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
-                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
-                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
-    else if (wave_emit)
-        MI_LAUNCH("tile_emit", tile_emit_wave_kernel<64>, dim3(mi_div_up(CN, 64 * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
-                  radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
-                  (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt);
+    // 16-bit tile keys: the caller does not want the sorted keys back (its tile_keys buffer is scratch: both 16-bit key
+    // buffers live in it), every tile id fits, and the sort is a classic one (the 16-bit kernels exist for that path only)
+    static const bool k16_on = [] { const char* e = getenv("MI3DGS_KEYS16"); return !(e && e[0] == '0'); }();
+    const bool k16 = k16_on && keys_scratch && wave_emit && !isect_ids_opt && n_tiles_total <= 65536u && cap >= 64u &&
+                     !(g_sort_mode == 1 || (g_sort_mode == 2 && cap <= os_max_keys()));
+    uint16_t* tk16 = (uint16_t*)tile_keys;
+#define WE_LAUNCH(SPW_, KT_, TK_) MI_LAUNCH("tile_emit", (tile_emit_wave_kernel<SPW_, KT_>), dim3(mi_div_up(CN, SPW_ * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, \
+        CN, n_live, rir, (uint32_t)N, sorted_ids, radii, splats, tile_size, tile_width, tile_height, height, cap, TK_, fi, status, counter, err, \
+        (uint32_t*)n_isect_dev, (uint32_t*)tiles_per_gauss_opt)
+    if (wave_emit && we_spw_for(CN) == 16) { if (k16) WE_LAUNCH(16, uint16_t, tk16); else WE_LAUNCH(16, uint32_t, tk); }
+    else if (wave_emit && we_spw_for(CN) == 32) { if (k16) WE_LAUNCH(32, uint16_t, tk16); else WE_LAUNCH(32, uint32_t, tk); }
+    else if (wave_emit) { if (k16) WE_LAUNCH(64, uint16_t, tk16); else WE_LAUNCH(64, uint32_t, tk); }
+#undef WE_LAUNCH
     else if (tight)
         MI_LAUNCH("tile_emit", (tile_emit_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, CN, n_live, rir, (uint32_t)N, sorted_ids,
                   nullptr, radii, splats, tile_size, tile_width, tile_height, height, cap, tk, fi, status, counter, err,
@@ -1783,6 +1831,21 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
         MI_LAUNCH("tile_emit_slow", tile_emit_slow_kernel, dim3(SLOW_BLOCKS), dim3(256), 0, st, ws.slow, slow_count, tile_size,
                   tile_width, height, cap, tk, fi);
     MI_LAUNCH_CHECK();
+    if (k16) {
+        int nbits = 1;
+        while ((1u << nbits) < n_tiles_total) nbits++;
+        uint16_t* tk16_b = tk16 + align_u32((size_t)cap);          // 2 x cap 16-bit keys fit the caller's cap 32-bit words
+        int in_b = 0;
+        rc = radix_sort_pairs_k16(tk16, fi, tk16_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st, "isect", z.isect);
+        if (rc) return rc;
+        const uint16_t* sorted_keys = in_b ? tk16_b : tk16;
+        if (in_b) MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
+        uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
+        MI_LAUNCH("tile_offsets", tile_offsets_kernel<uint16_t>, dim3(mi_div_up(mi_div_up(g, 4), 256)), dim3(256), 0, st, sorted_keys,
+                  (const uint32_t*)n_isect_dev, cap, n_tiles_total, isect_offsets);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
     return bin_sort_and_offsets(ws, tk, fi, n_isect_dev, cap, n_tiles_total, splats, isect_offsets, isect_ids_opt, st, z.isect);
 }
 

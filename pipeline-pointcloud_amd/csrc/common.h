@@ -43,6 +43,7 @@
 #define MI_FLAG_ANTIALIASED 4     // rasterize_mode == "antialiased": opacity *= compensation
 #define MI_BIN_TIGHT 1             // mi3dgs_bin_*: `tight` argument, bit 0 = exact ellipse culling
 #define MI_BIN_RADII_IN_RECORDS 2  //   bit 1 = take the radii from record slots SP_RX / SP_RY (written by project_fwd)
+#define MI_BIN_KEYS_SCRATCH 4      //   bit 2 (mi3dgs_bin_tiles) = the caller does not read tile_keys back: the buffer is scratch (16-bit keys)
 #define MI_FLAG_PROBE 16          // project_bwd_adam: same code under another kernel name (placement search)
 
 #define ALPHA_THRESHOLD (1.0f / 255.0f)

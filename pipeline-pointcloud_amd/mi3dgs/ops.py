@@ -145,15 +145,18 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,
               want_isect_ids: bool = False, want_tiles_per_gauss: bool = False, tight: bool = False,
-              fused: bool = True, depth_keys: Optional[torch.Tensor] = None, radii_in_records: bool = False):
+              fused: bool = True, depth_keys: Optional[torch.Tensor] = None, radii_in_records: bool = False,
+              want_tile_keys: bool = True):
     """Tile binning.  tight=False reproduces gsplat's bounding-box tile lists; tight=True drops
     the (tile, splat) pairs the ellipse sigma <= ln(255 o) cannot reach (identical renders and
     gradients, fewer intersections).  With max_isect=None the intersection count is read back (one host
     sync) and the outputs are sized exactly; otherwise outputs hold max_isect entries and
     the live count stays on the device (no sync).  depth_keys [C,N] int32 (fused path only): the sort
     keys mi3dgs_project_fwd wrote beside its records; they are consumed.  radii_in_records: the records come from
-    mi3dgs_project_fwd (radii in slots 11, 12): one gather per splat in the emit pass."""
-    tight = int(bool(tight)) | (2 if radii_in_records else 0)
+    mi3dgs_project_fwd (radii in slots 11, 12): one gather per splat in the emit pass.  want_tile_keys=False (fused
+    path): the sorted tile keys are not returned and their buffer is scratch, which lets the library sort 16-bit keys
+    when every tile id fits (the training step and the renderer only use flatten_ids and isect_offsets)."""
+    tight = int(bool(tight)) | (2 if radii_in_records else 0) | (0 if want_tile_keys else 4)
     Cn, N = radii.shape[0], radii.shape[1]
     dev = radii.device
     tw, th = math.ceil(width / tile_size), math.ceil(height / tile_size)
@@ -175,8 +178,8 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
         _lib.call("mi3dgs_bin_tiles", Cn, N, _p(radii), _p(splats), tile_size, tw, th, int(height), int(tight),
                   _p(n_isect), cap, _p(flatten_ids), _p(tile_keys), _p(offsets), _p(isect_ids), _p(tpg), _p(depth_keys),
                   _p(ws), ws.numel(), st)
-        out = dict(n_isect=n_isect, flatten_ids=flatten_ids, tile_keys=tile_keys, isect_offsets=offsets,
-                   tile_width=tw, tile_height=th, max_isect=cap)
+        out = dict(n_isect=n_isect, flatten_ids=flatten_ids, tile_keys=tile_keys if want_tile_keys else None,
+                   isect_offsets=offsets, tile_width=tw, tile_height=th, max_isect=cap)
         if want_isect_ids:
             out["isect_ids"] = isect_ids
         if want_tiles_per_gauss:

@@ -258,7 +258,7 @@ class Trainer:
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=cap, tight=self.cfg.tight_tiles,
-                                fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True)
+                                fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True, want_tile_keys=False)
         if self.cfg.auto_isect_capacity and self.cfg.max_isect is None:
             torch.maximum(self._isect_peak, binning["n_isect"], out=self._isect_peak)
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)

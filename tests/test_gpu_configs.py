@@ -134,6 +134,12 @@ def test_full_size_binning_bit_exact_and_raster_properties(dev, kind, cam):
                        want_tiles_per_gauss=True, radii_in_records=True)      # exactly the training step's call
     It = int(bt["n_isect"].item())
     assert 0 < It <= I and It == int(bt["tiles_per_gauss"].sum())
+    # the training step's and the renderer's call does not ask for the sorted tile keys back: the library then sorts 16-bit
+    # keys (garden and 6m are above the switch-over to the classic passes, lego below it) -- the same lists bit for bit
+    b16 = ops.bin_tiles(radii, splats, W, H, 16, max_isect=I + 4096, tight=True, fused=True, depth_keys=keys.clone(),
+                        radii_in_records=True, want_tile_keys=False)
+    assert b16["tile_keys"] is None and int(b16["n_isect"].item()) == It
+    assert torch.equal(b16["flatten_ids"][:It], bt["flatten_ids"][:It]) and torch.equal(b16["isect_offsets"], bt["isect_offsets"])
     tk, fi = bt["tile_keys"][:It].long(), bt["flatten_ids"][:It].long()
     assert bool((tk[1:] >= tk[:-1]).all())
     d = splats.view(-1, ops.SPLAT_STRIDE)[fi, 9]
