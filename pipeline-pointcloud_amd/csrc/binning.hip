@@ -1227,7 +1227,13 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(uint32_t CN_cap, const u
 // 9.7e7 VALU instructions (the block kernel: 5.3e7) and 316 + 24 us; kept out of the tree.
 // Same output, bit for bit, as the two-phase path: tests/test_gpu_parity.py::test_fused_binning_equals_the_two_phase_path,
 // tests/test_gpu_configs.py (15 - 40 M keys).
-constexpr int WE_WAVES = 16;              // waves per block = 64-splat chunks per ticket
+// Waves per block = 64-splat chunks per ticket.  The kernel needs 106 scalar registers, i.e. at most SEVEN waves per SIMD
+// (800 SGPRs per SIMD in blocks of 16): a 16-wave block takes four per SIMD, so only ONE such block fitted a CU although two
+// fit its LDS and vector registers -- the phase stamps (tools/emit_probe.py) showed generations of ~300 blocks, 28 us each,
+// five of them.  8-wave blocks: three per CU (24 waves; 12-wave blocks the same), 152 -> 127 us; 6- and 4-wave blocks lose
+// again to the ticket word (145, 151 us).  Capping the scalar registers for eight waves per SIMD (four blocks per CU, 39
+// SGPR spills) did not help: 132 us.
+constexpr int WE_WAVES = 8;
 constexpr int WE_CACHE = 6;               // item chunks whose spans stay in registers between count and emit (384 rows)
 constexpr int WE_GROUPS = 128;            // bitmap words per item chunk: 64 items x at most 128 tile columns / 64 (images up to 2 048 px wide; wider ones take the block kernel)
 struct WaveEmitLds {
@@ -1253,6 +1259,17 @@ inline int we_spw_for(uint32_t CN) {
     return CN <= we_small_splats() ? 16 : big;
 }
 inline size_t we_chain_entries(uint32_t CN) { return (size_t)WE_WAVES * (size_t)mi_div_up(CN, (long long)we_spw_for(CN) * WE_WAVES); }
+
+#ifdef MI3DGS_OS_STAMPS
+// Probe build only (tools/emit_probe.py): wall-clock stamps (100 MHz) of the phases of waves 0 and 15 of every block.
+__device__ unsigned long long g_we_stamps[4096][2][8];
+#define WE_STAMP(i) do { if (lane == 0 && (wv == 0 || wv == WE_WAVES - 1) && s_blk < 4096) g_we_stamps[s_blk][wv ? 1 : 0][i] = wall_clock64(); } while (0)
+extern "C" int mi3dgs_debug_read_we_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_we_stamps), bytes < sizeof(g_we_stamps) ? bytes : sizeof(g_we_stamps));
+}
+#else
+#define WE_STAMP(i) do { } while (0)
+#endif
 
 template <int SPW, typename KT>
 __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
@@ -1305,6 +1322,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         arrive(0u);
         return;
     }
+    WE_STAMP(0);
     const uint32_t i = wid * (uint32_t)SPW + (uint32_t)lane;
     const bool owns = lane < SPW && i < CN;   // this lane brings in a splat
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1334,6 +1352,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         L.id[lane] = idx;
         L.cnt[lane] = 0u;
     }
+    WE_STAMP(1);                              // records gathered, geometry in LDS
     const uint32_t rincl = wave_incl_scan_u32(rows);
     L.row_base[lane] = rincl - rows;
     const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
@@ -1376,6 +1395,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         if (tiles_out && (span >> 16)) atomicAdd(&L.cnt[g], span >> 16);
     }
     const uint32_t total = wave_sum_u32(mine);
+    WE_STAMP(2);                              // counted
     // ---- chain
     uint32_t base = 0u;
     if (status) {
@@ -1414,6 +1434,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
             base = s_excl + part;
         }
     }
+    WE_STAMP(3);                              // base known
     if (wid == (CN - 1u) / (uint32_t)SPW && lane == 0) {
         uint32_t tot = base + total;
         if (tot > cap) { atomicOr(chain_err, 4u); tot = cap; }
@@ -1475,6 +1496,12 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         if (j0 + lane < R) eval_item(j0 + (uint32_t)lane, g, span);
         emit_chunk(j0 + (uint32_t)lane, g, span);
     }
+    WE_STAMP(4);                              // stores issued
+#ifdef MI3DGS_OS_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    WE_STAMP(5);
+    if (lane == 0 && (wv == 0 || wv == WE_WAVES - 1) && s_blk < 4096) { g_we_stamps[s_blk][wv ? 1 : 0][6] = R; g_we_stamps[s_blk][wv ? 1 : 0][7] = total; }
+#endif
 }
 
 // Emission of the big splats listed by tile_emit_kernel: one wave per splat, waves stride over the list.
