@@ -1833,8 +1833,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     uint32_t* tk = (uint32_t*)tile_keys;
     uint32_t* fi = (uint32_t*)flatten_ids;
     const bool wave_emit = tight && g_emit_mode == 1 && tile_width <= WE_GROUPS;
-    // 16-bit tile keys: the caller does not want the sorted keys back (its tile_keys buffer is scratch: both 16-bit key
-    // buffers live in it), every tile id fits, and the sort is a classic one (the 16-bit kernels exist for that path only)
+    // 16-bit tile keys: the caller does not want the sorted keys back (its tile_keys buffer is scratch), every tile id fits, and the sort is a classic one (the 16-bit kernels exist for that path only)
     static const bool k16_on = [] { const char* e = getenv("MI3DGS_KEYS16"); return !(e && e[0] == '0'); }();
     const bool k16 = k16_on && keys_scratch && wave_emit && !isect_ids_opt && n_tiles_total <= 65536u && cap >= 64u &&
                      !(g_sort_mode == 1 || (g_sort_mode == 2 && cap <= os_max_keys()));
@@ -1861,7 +1860,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     if (k16) {
         int nbits = 1;
         while ((1u << nbits) < n_tiles_total) nbits++;
-        uint16_t* tk16_b = tk16 + align_u32((size_t)cap);          // 2 x cap 16-bit keys fit the caller's cap 32-bit words
+        uint16_t* tk16_b = (uint16_t*)ws.tk_b;                      // the workspace's second key buffer (cap 32-bit words, half used)
         int in_b = 0;
         rc = radix_sort_pairs_k16(tk16, fi, tk16_b, ws.fi_b, (const uint32_t*)n_isect_dev, cap, nbits, ws.tmp, &in_b, st, "isect", z.isect);
         if (rc) return rc;
