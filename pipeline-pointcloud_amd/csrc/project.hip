@@ -620,7 +620,10 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             slice_load(slice, shN + 45 * (long long)n0, count, lane);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // same-wave LDS hand-off: ordering only
+    // same-wave LDS hand-off: ordering only.  Wavefront scope: a workgroup-scope fence also waits for every global access in
+    // flight (s_waitcnt vmcnt(0)), which put a full memory round trip between the slice and the loads behind it.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     GeoGrad G;
 #pragma unroll
@@ -776,7 +779,8 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // (not workgroup: that waits for the 42 small-group stores)
+    __builtin_amdgcn_wave_barrier();
     if (!FUSE) {
         slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
     } else if (!(flags & 128)) {
