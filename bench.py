@@ -400,6 +400,23 @@ def main():
             else:
                 ach = stages[dom]["alg_GBps"]
                 roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, **common)
+                # Beside the pin-rate peak: what a plain 1 R : 1 W copy of 1 GiB gets from THIS box's HBM (extra field, measured
+                # live; boxes differ by ~15 %).  The dominant kernel reads 1.8 GB and writes 1.4 GB per launch.
+                try:
+                    ca = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+                    cb = torch.empty_like(ca)
+                    cb.copy_(ca)
+                    ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ce0.record()
+                    for _ in range(5):
+                        cb.copy_(ca)
+                    ce1.record()
+                    torch.cuda.synchronize()
+                    roof["copy_GBps_this_box"] = round(5 * 2 * ca.numel() * 4 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9, 1)
+                    del ca, cb
+                except Exception as e:      # out of memory on a crowded card: the field is informational
+                    roof["copy_GBps_this_box"] = None
+                    log(f"copy probe skipped: {e}")
             # ---- the render path's dominant kernel, same accounting (its own profiled launches)
             torch.cuda.synchronize()
             _lib.profile_enable(True)
