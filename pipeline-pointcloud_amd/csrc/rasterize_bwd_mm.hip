@@ -241,10 +241,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
     constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
     __shared__ StagedBwdMM<ABSGRAD> L;
-    const int t = blockIdx.x;
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -444,7 +444,7 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
 #define LAUNCH_MM(BG, AG, E)                                                                                                 \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
-              v_render, v_alphas, v_splats)
+              v_render, v_alphas, v_splats, raster_bands())
     if (experiment == 4) {           // wave-flush variant (correct results)
         if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4); else LAUNCH_MM(true, false, 4); }
         else { if (absgrad) LAUNCH_MM(false, true, 4); else LAUNCH_MM(false, false, 4); }

@@ -39,9 +39,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
-    int32_t* __restrict__ last_ids) {
+    int32_t* __restrict__ last_ids, int bands) {
     __shared__ Staged L;
-    const int t = blockIdx.x;
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
     __shared__ StagedBwd L;
-    const int t = blockIdx.x;
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -320,7 +320,7 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
     using namespace mfma_raster;
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,     \
-              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids)
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands())
     (void)prefetch;      // (a variant with the next sub-batch's MFMAs issued early was measured slower and is gone)
     if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
 #undef LAUNCH_FWD
@@ -347,7 +347,7 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
 #define LAUNCH_BWD(BG, AG, PF)                                                                                             \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, PF>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
-              v_render, v_alphas, v_splats)
+              v_render, v_alphas, v_splats, raster_bands())
 #define LAUNCH_BWD2(BG, AG) do { if (prefetch) LAUNCH_BWD(BG, AG, true); else LAUNCH_BWD(BG, AG, false); } while (0)
     if (backgrounds) { if (absgrad) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
     else { if (absgrad) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
