@@ -244,7 +244,8 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
     constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
     __shared__ StagedBwdMM<ABSGRAD> L;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
+    if (t < 0) return;
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -442,7 +443,7 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
                         const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st) {
     using namespace mfma_raster;
 #define LAUNCH_MM(BG, AG, E)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
     if (experiment == 4) {           // wave-flush variant (correct results)

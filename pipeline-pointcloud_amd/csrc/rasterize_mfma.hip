@@ -41,7 +41,8 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
     int32_t* __restrict__ last_ids, int bands) {
     __shared__ Staged L;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
+    if (t < 0) return;
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
     __shared__ StagedBwd L;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands);
+    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
+    if (t < 0) return;
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -319,7 +321,7 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           const float* backgrounds, float* render, float* alphas, int32_t* last_ids, int prefetch, hipStream_t st) {
     using namespace mfma_raster;
 #define LAUNCH_FWD(BG)                                                                                                    \
-    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,     \
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands())
     (void)prefetch;      // (a variant with the next sub-batch's MFMAs issued early was measured slower and is gone)
     if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
@@ -345,7 +347,7 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
                                    backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, variant >= 10 ? variant - 10 : 0, st);
     const int prefetch = variant == 2;
 #define LAUNCH_BWD(BG, AG, PF)                                                                                             \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, PF>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, PF>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
 #define LAUNCH_BWD2(BG, AG) do { if (prefetch) LAUNCH_BWD(BG, AG, true); else LAUNCH_BWD(BG, AG, false); } while (0)
