@@ -1319,6 +1319,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         }
     };
     if (wid * (uint32_t)SPW >= CN) {          // past the end of the sorted list: an empty member of its block
+        if (CN == 0u && wid == 0u && lane == 0) *n_isect_out = 0u;     // nothing visible: the count is written here (no clear in front of the kernel)
         arrive(0u);
         return;
     }
@@ -1815,7 +1816,8 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     bin_zero_layout(CN, cap, ws.zero, &z);
     MI_HIP(hipMemsetAsync(ws.zero, 0, ws.zero_words * sizeof(uint32_t), st));
     uint32_t* n_live = z.n_live;
-    MI_HIP(hipMemsetAsync(n_isect_dev, 0, 4, st));
+    const bool wave_emit_path = (tight & MI_BIN_TIGHT) && g_emit_mode == 1 && tile_width <= WE_GROUPS;
+    if (!wave_emit_path) MI_HIP(hipMemsetAsync(n_isect_dev, 0, 4, st));       // (the wave-granular emit always writes the count itself)
     if (tiles_per_gauss_opt) MI_HIP(hipMemsetAsync(tiles_per_gauss_opt, 0, (size_t)CN * 4, st));
     int in_b = 0;
     int rc = radix_sort_pairs(dkeys, ws.ids_a, ws.dkeys_b, ws.ids_b, nullptr, CN, 32, ws.tmp, &in_b, st, "depth",

@@ -178,6 +178,10 @@ def test_binning_empty_scene(dev):
     assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
     b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=1000)       # fused path
     assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
+    # the training step's call (wave-granular emit): the kernel itself writes the zero count, nothing clears it in front
+    for _ in range(2):
+        b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16, max_isect=1000, tight=True, want_tile_keys=False)
+        assert int(b["n_isect"].item()) == 0 and int(b["isect_offsets"].abs().sum()) == 0
     bg = torch.rand(2, 3, device=dev)
     r, a, _ = ops.rasterize_fwd(splats, b, sc.width, sc.height, 16, bg)
     assert torch.equal(r, bg[:, None, None, :].expand_as(r)) and float(a.abs().max()) == 0
