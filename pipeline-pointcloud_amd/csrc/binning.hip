@@ -1565,31 +1565,33 @@ template <typename KT>
 __global__ __launch_bounds__(256) void tile_offsets_kernel(const KT* __restrict__ keys,
                                                            const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                            uint32_t n_tiles_total, int32_t* __restrict__ offsets) {
+    constexpr int KPT = 16 / (int)sizeof(KT);          // keys per thread: one 16-byte load (4 x u32 or 8 x u16)
     uint32_t n = live_count(n_ptr, cap);
-    uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * KPT;
     if (n == 0) {
-        for (uint32_t t = i0; t < i0 + 4 && t < n_tiles_total; t++) offsets[t] = 0;
+        for (uint32_t t = i0; t < i0 + KPT && t < n_tiles_total; t++) offsets[t] = 0;
         return;
     }
     if (i0 >= n) return;
-    uint32_t k[4];
-    if (i0 + 4 <= n) {
+    uint32_t k[KPT];
+    if (i0 + KPT <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
         if (sizeof(KT) == 4) {
-            uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
             k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
         } else {
-            uint2 q = *reinterpret_cast<const uint2*>(keys + i0);
-            k[0] = q.x & 0xFFFFu; k[1] = q.x >> 16; k[2] = q.y & 0xFFFFu; k[3] = q.y >> 16;
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) { k[(2 * j) % KPT] = w[j] & 0xFFFFu; k[(2 * j + 1) % KPT] = w[j] >> 16; }
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? keys[i0 + j] : 0u;
+        for (int j = 0; j < KPT; j++) k[j] = i0 + j < n ? (uint32_t)keys[i0 + j] : 0u;
     }
-    uint32_t prev = i0 == 0 ? 0u : keys[i0 - 1];
+    uint32_t prev = i0 == 0 ? 0u : (uint32_t)keys[i0 - 1];
     if (i0 == 0)
         for (uint32_t t = 0; t <= k[0]; t++) offsets[t] = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < KPT; j++) {
         uint32_t i = i0 + j;
         if (i >= n) break;
         if (i > 0)
@@ -1869,7 +1871,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
         const uint16_t* sorted_keys = in_b ? tk16_b : tk16;
         if (in_b) MI_HIP(hipMemcpyAsync(fi, ws.fi_b, (size_t)cap * 4, hipMemcpyDeviceToDevice, st));
         uint32_t g = cap > n_tiles_total ? cap : n_tiles_total;
-        MI_LAUNCH("tile_offsets", tile_offsets_kernel<uint16_t>, dim3(mi_div_up(mi_div_up(g, 4), 256)), dim3(256), 0, st, sorted_keys,
+        MI_LAUNCH("tile_offsets", tile_offsets_kernel<uint16_t>, dim3(mi_div_up(mi_div_up(g, 8), 256)), dim3(256), 0, st, sorted_keys,
                   (const uint32_t*)n_isect_dev, cap, n_tiles_total, isect_offsets);
         MI_LAUNCH_CHECK();
         return 0;
