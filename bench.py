@@ -56,10 +56,6 @@ def parse():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
-    ap.add_argument("--placement-tuning", action="store_true",
-                    help="A/B: run Trainer.tune_placement first (start-up search over the HBM placement of the parameter / "
-                         "moment arrays; off by default since round 2: the flat model layout needs no lottery)")
-    ap.add_argument("--no-placement-tuning", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling, now the default
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
@@ -131,8 +127,6 @@ def build_workload(args, rank, dev):
                                           dataclasses.replace(cfg, capacity=n, fuse_adam=ctx.world == 1), ctx=ctx)
     else:
         tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
-    if args.placement_tuning:
-        tr.tune_placement(log=log)   # part of start-up, like the capacity sizing below; not inside the timed steps
     tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
     if not args.sync_isect:
         # size the intersection buffers once (one sync here, none in the loop): 1.5x the worst view
@@ -211,6 +205,76 @@ def cpu_baseline_cpu_tensors(P, vm, K, gt, W, H, crop_div=6):
                        f"= {full:.1f} s; Adam not included")
 
 
+def box_info() -> dict:
+    """What kind of box this line was measured on ("slow box" has to be a recorded fact, not a label):
+    partition modes, clock tables with the active level, power cap -- plain sysfs reads (amdgpu), taken before anything
+    touches the GPU; no child process, no smi library."""
+    import glob
+    out = {"cpu": None, "gpus": []}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                out["cpu"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if rd(os.path.join(dev, "vendor")) != "0x1002":
+            continue
+        e = {"card": os.path.basename(os.path.dirname(dev))}
+        for k in ("current_compute_partition", "current_memory_partition", "mem_info_vram_total", "mem_busy_percent"):
+            v = rd(os.path.join(dev, k))
+            if v is not None:
+                e[k] = v
+        for k in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+            v = rd(os.path.join(dev, k))
+            if v is not None:
+                lv = [x.strip() for x in v.splitlines()]
+                e[k] = {"levels": [x.rstrip(" *") for x in lv], "active": [x.rstrip(" *") for x in lv if x.endswith("*")]}
+        for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+            for k in ("power1_cap", "power1_cap_max", "power1_average", "power1_input", "freq1_input", "freq2_input"):
+                v = rd(os.path.join(hw, k))
+                if v is not None:
+                    e[k] = v
+        out["gpus"].append(e)
+    # identical cards collapse into one entry with a count
+    uniq = []
+    for e in out["gpus"]:
+        body = {k: v for k, v in e.items() if k not in ("card", "power1_average", "power1_input", "mem_busy_percent")}
+        for u in uniq:
+            if u["same"] == body:
+                u["cards"].append(e["card"])
+                break
+        else:
+            uniq.append({"same": body, "cards": [e["card"]]})
+    out["gpus"] = [dict(u["same"], cards=u["cards"]) for u in uniq]
+    return out
+
+
+def hbm_yardstick(dev, n_read, n_write, mib_per_array=256, reps=5):
+    """GB/s of the library's own 16-byte-per-lane stream (mi3dgs_debug_hbm_stream) on THIS device: n_read arrays read, their
+    sum written to n_write arrays.  (1, 1) is the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s."""
+    from mi3dgs import _lib, ops
+    fl = (mib_per_array << 20) // 4
+    buf = torch.empty((n_read + n_write) * fl, dtype=torch.float32, device=dev).normal_()
+    st = ops._stream(dev)
+    _lib.call("mi3dgs_debug_hbm_stream", ops._p(buf), fl, n_read, n_write, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.call("mi3dgs_debug_hbm_stream", ops._p(buf), fl, n_read, n_write, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(reps * (n_read + n_write) * fl * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def host_threads() -> int:
     """Threads the CPU leg may use: the process's CPU affinity, capped at the 16-core share a
     one-GPU box gets (os.cpu_count() reports the whole host and oversubscribes it)."""
@@ -258,6 +322,7 @@ def main():
     args = parse()
     if args.cpu_leg:
         return cpu_leg_main(args.cpu_leg)
+    box = box_info()            # before anything touches the GPU
     rank, world, local = setup_dist(args.gpus, args.rehearse)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     dev = torch.device("cuda", local)
@@ -400,21 +465,14 @@ def main():
             else:
                 ach = stages[dom]["alg_GBps"]
                 roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, **common)
-                # Beside the pin-rate peak: what a plain 1 R : 1 W copy of 1 GiB gets from THIS box's HBM (extra field, measured
-                # live; boxes differ by ~15 %).  The dominant kernel reads 1.8 GB and writes 1.4 GB per launch.
+                # Beside the pin-rate peak: what the library's OWN float4 streams get from THIS box's HBM, measured live (the
+                # guide measures 6.29 TB/s for the copy): the plain 1 R : 1 W copy and the dominant kernel's own 5 R : 4 W mix
+                # (it reads 1.78 GB and writes 1.45 GB per launch).  frac_of_own_stream = the kernel against that mix.
                 try:
-                    ca = torch.empty(256 << 20, dtype=torch.float32, device=dev)
-                    cb = torch.empty_like(ca)
-                    cb.copy_(ca)
-                    ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ce0.record()
-                    for _ in range(5):
-                        cb.copy_(ca)
-                    ce1.record()
-                    torch.cuda.synchronize()
-                    roof["copy_GBps_this_box"] = round(5 * 2 * ca.numel() * 4 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9, 1)
-                    del ca, cb
-                except Exception as e:      # out of memory on a crowded card: the field is informational
+                    roof["copy_GBps_this_box"] = hbm_yardstick(dev, 1, 1)
+                    roof["mix_5r4w_GBps_this_box"] = hbm_yardstick(dev, 5, 4, mib_per_array=128)
+                    roof["frac_of_own_stream"] = round(ach / roof["mix_5r4w_GBps_this_box"], 3)
+                except Exception as e:      # out of memory on a crowded card: the fields are informational
                     roof["copy_GBps_this_box"] = None
                     log(f"copy probe skipped: {e}")
             # ---- the render path's dominant kernel, same accounting (its own profiled launches)
@@ -476,7 +534,12 @@ def main():
             "metric": "3DGS training iterations/s @1080p (render FPS reported alongside)",
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "f32 arithmetic and accumulation throughout, except the transport of rasterize_bwd's per-splat pixel "
+                          "sums to their f32 accumulators: two bf16 terms per addend (16-bit significand, <= 2^-16 relative, "
+                          "unbiased; profiles/r03_bwd_terms_ab.txt has the three-term A/B); alpha evaluation uses three-term "
+                          "bf16 coefficients (24 bits, exact products)",
+            "data": "synthetic", "box": box,
             "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, {what}",
                        "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
                        "parallelism": par, "mode": args.mode,

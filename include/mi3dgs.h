@@ -42,16 +42,22 @@ extern "C" {
 #define MI3DGS_FLAG_LOG_SCALES 1   /* scales are log-space parameters; exp() fused */
 #define MI3DGS_FLAG_LOGIT_OPAC 2   /* opacities are logits; sigmoid() fused */
 #define MI3DGS_FLAG_ANTIALIASED 4  /* rasterize_mode "antialiased": opacity *= compensation */
-#define MI3DGS_FLAG_PROBE 16       /* mi3dgs_project_bwd_adam: identical code under a kernel name of its
-                                    * own, for the timed no-op launches of a placement search */
 
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
 #define MI3DGS_COLOR_PER_GAUSSIAN 1 /* colors[N,3] */
 #define MI3DGS_COLOR_PER_CAMERA 2  /* colors[C,N,3] */
 
+/* Environment variables the PRODUCT library reads, all of them size thresholds between code paths that give the same
+ * results (tests/test_cabi_cpu.py checks that the binary holds no other MI3DGS_ name):
+ *   MI3DGS_OS_SMALL_KEYS      sorts up to this many keys use 2 048-key onesweep tiles (default 512 K)
+ *   MI3DGS_OS_MAX_KEYS        sorts above this many keys use the classic radix passes (default 4 M)
+ *   MI3DGS_EMIT_SMALL_SPLATS  up to this many Gaussians the tile emit gives a wave 16 splats instead of 64 (default 128 K)
+ *   MI3DGS_KEYS16=0           never sort 16-bit tile keys
+ * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
+ * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);
-int mi3dgs_abi_version(void);
+int mi3dgs_abi_version(void);      /* 4 */
 int mi3dgs_splat_stride(void);
 int mi3dgs_grad_stride(void);
 
@@ -188,7 +194,8 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
  * Numerics: log2 alpha of a (pixel, splat) pair is evaluated by the forward's own instruction sequence (three-term bf16
  * coefficients against an exact bf16 basis, f32 accumulation), so forward and backward take the same alpha >= 1/255 decision;
  * the per-splat sums over a tile's pixels are carried to their f32 accumulators as two bf16 terms per value (relative error
- * <= 2^-16 per term, unbiased).  mi3dgs_debug_set_raster_mode(3) selects the all-f32 reduction of the same sums. */
+ * <= 2^-16 per term, unbiased; bench.py says so in `dtype_note`).  The all-f32 reduction of the same sums exists in the
+ * experiments library only (mi3dgs_debug_set_raster_mode(3) there), as the yardstick of tests/test_gpu_configs.py. */
 int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width,
                          int tile_height, const float* splats, const int32_t* isect_offsets,
                          const int32_t* flatten_ids, const int32_t* n_isect_dev,
@@ -196,9 +203,9 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
                          const float* v_render, const float* v_alphas, int absgrad, float* v_splats,
                          void* stream);
 
-/* A/B switch: 1 (default) = the rasterisers whose pixel x splat quadratic forms run on the matrix pipe
- * (v_mfma_f32_32x32x2_f32, csrc/rasterize_mfma.hip), 0 = the round-1 all-VALU kernels, 2 = as 1 with the tile list
- * fetched one batch ahead (measured slower).  Forward and backward must run in the same mode (0 vs 1/2). */
+/* Product library: accepts 1 (the MFMA rasterisers, the only ones it holds) and fails for anything else.  Experiments
+ * library: 0 = round-1 all-VALU kernels, 3 = f32 reduce-scatter backward, 4 = three-term bf16 backward, 14 = wave-flush
+ * backward, 11..13 = timing experiments with wrong results (csrc/rasterize.hip). */
 int mi3dgs_debug_set_raster_mode(int mode);
 
 /* ---- loss ----------------------------------------------------------------------------
@@ -218,9 +225,15 @@ int mi3dgs_scale_reg(int N, const float* scales_log, float weight, float max_rat
 /* ---- optimiser -----------------------------------------------------------------------
  * Replaces torch.optim.Adam over the Gaussian parameter groups: one launch for up to 8
  * flat segments.  The pointer arrays are HOST arrays of device pointers. */
+/* grad_scale: every gradient is multiplied by it on the way in (1 for a single GPU; 1 / world behind a sum
+ * reduce-scatter, reference main.py:1318-1347). */
 int mi3dgs_adam_step(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* numel, const float* lrs, int step,
-                     float beta1, float beta2, float eps, void* stream);
+                     float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* HBM yardstick for the bench line (roofline.copy_GBps_this_box): a 16-byte-per-lane stream that reads n_read arrays and
+ * writes their sum to n_write arrays; buf holds (n_read + n_write) arrays of floats_per_array floats, reads first.
+ * (n_read, n_write) in {(1,1) copy, (2,1), (4,3), (5,4) the mix of mi3dgs_project_bwd_adam, (1,0), (0,1)}. */
+int mi3dgs_debug_hbm_stream(float* buf, long long floats_per_array, int n_read, int n_write, void* stream);
 
 /* ---- adaptive density control --------------------------------------------------------
  * Replaces gsplat DefaultStrategy._grow_gs/_prune_gs and strategy.ops duplicate / split /

@@ -240,9 +240,10 @@ inline uint32_t os_small_keys() {
     static const uint32_t v = [] { const char* e = getenv("MI3DGS_OS_SMALL_KEYS"); return e ? (uint32_t)atol(e) : (512u << 10); }();
     return v;
 }
-inline uint32_t os_nolookback() { const char* e = getenv("MI3DGS_OS_NOLOOKBACK"); return (e && e[0] == '1') ? 0x40000000u : 0u; }
-inline int os_big_items() {                        // (A/B: MI3DGS_OS_BIG_ITEMS=16 halves the big tile)
-    static const int v = [] { const char* e = getenv("MI3DGS_OS_BIG_ITEMS"); return (e && atoi(e) == 16) ? 16 : OS_ITEMS_BIG; }();
+// (experiments build only: sort without its prefix -- WRONG results, the bound for the look-back's cost)
+inline uint32_t os_nolookback() { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_NOLOOKBACK"); return (e && e[0] == '1') ? 0x40000000u : 0u; }
+inline int os_big_items() {                        // (experiments build, A/B: MI3DGS_OS_BIG_ITEMS=16 halves the big tile)
+    static const int v = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_BIG_ITEMS"); return (e && atoi(e) == 16) ? 16 : OS_ITEMS_BIG; }();
     return v;
 }
 inline int os_items_for(uint32_t cap) { return cap <= os_small_keys() ? OS_ITEMS_SMALL : os_big_items(); }
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __r
                                                              int per, int nbits, uint32_t* __restrict__ ghist /*[passes][256]*/,
                                                              uint32_t* __restrict__ n_live_out) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
+    __shared__ uint32_t s_scan4[4];
     uint32_t n = live_count(n_ptr, cap);
     constexpr int OS_TILE = RS_THREADS * OS_ITEMS;
     uint32_t base = blockIdx.x * OS_TILE;
@@ -474,9 +476,16 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_kernel(const uint32_t* __r
         if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c);
     }
     if (DROP) {
-        // the block's live keys = the sum of any one pass's counters
+        // the block's live keys = the sum of any one pass's counters.
+        // The scan's four-word scratch is its OWN array.  Until round 3 it was h[1]: lane 63 of wave w stored its partial sum
+        // into h[1][w] while threads 1..3 of wave 0 could still be on their way to reading h[1][1..3] in the loop above (no
+        // barrier in between), so once in a few thousand blocks the GLOBAL histogram of pass 1 got a wave's key count
+        // (~2 000) instead of a digit's (~32) for digit 1, 2 or 3: every later digit's output range of that pass moved up,
+        // ~2 000 slots kept stale pairs and as many real ones landed beyond the live count -- a depth-sorted list with a
+        // few thousand duplicated / missing splats for ONE call (tests/test_gpu_configs.py [garden-0]: n_isect 16 085 932
+        // instead of 15 980 980, once in ~15 suite runs; DESIGN.md "the [garden-0] failure").
         uint32_t tot;
-        block_excl_scan_u32(h[0][threadIdx.x], &tot, h[1]);
+        block_excl_scan_u32(h[0][threadIdx.x], &tot, s_scan4);
         if (threadIdx.x == 0 && tot) atomicAdd(n_live_out, tot);
     }
 }
@@ -805,7 +814,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
             else if (os_big_items() == 16) MI_LAUNCH(htag, (os_hist_kernel<false, 16>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         }
-        static const bool wide = [] { const char* e = getenv("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
+        static const bool wide = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
@@ -1255,7 +1264,7 @@ inline uint32_t we_small_splats() {
     return v;
 }
 inline int we_spw_for(uint32_t CN) {
-    static const int big = [] { const char* e = getenv("MI3DGS_EMIT_SPW"); int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
+    static const int big = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_EMIT_SPW"); int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
     return CN <= we_small_splats() ? 16 : big;
 }
 inline size_t we_chain_entries(uint32_t CN) { return (size_t)WE_WAVES * (size_t)mi_div_up(CN, (long long)we_spw_for(CN) * WE_WAVES); }
@@ -1314,8 +1323,13 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         old_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)old_mask);
         if (status && (old_mask | (1u << wv)) == FULL_) {
             const uint32_t bt = wave_sum_u32(lane < WE_WAVES ? s_tot[lane] : 0u);
+            // atomic MAX, not a store: this word has a second writer (wave 0's inclusive prefix, flag 2, below), a different
+            // wave whose store is not ordered against this one.  With the flag in the top bits max() makes the word
+            // monotonic -- 0 -> total -> inclusive, whichever write lands first -- so a reader can never find an entry
+            // going back from "inclusive" to "total" (either value is correct on its own; the max removes the case
+            // distinction from the audit of VERDICT r2 #1)
             if (lane == 0)
-                __hip_atomic_store(status + s_blk, chain_pack(s_blk == 0 ? 2u : 1u, bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(status + s_blk, chain_pack(s_blk == 0 ? 2u : 1u, bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     if (wid * (uint32_t)SPW >= CN) {          // past the end of the sorted list: an empty member of its block
@@ -1417,7 +1431,7 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
                 }
                 const uint32_t bt = wave_sum_u32(lane < WE_WAVES ? s_tot[lane] : 0u);
                 if (lane == 0)
-                    __hip_atomic_store(status + b, chain_pack(2u, excl_b + bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_max(status + b, chain_pack(2u, excl_b + bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             base = excl_b;
         } else {

@@ -44,7 +44,18 @@
 #define MI_BIN_TIGHT 1             // mi3dgs_bin_*: `tight` argument, bit 0 = exact ellipse culling
 #define MI_BIN_RADII_IN_RECORDS 2  //   bit 1 = take the radii from record slots SP_RX / SP_RY (written by project_fwd)
 #define MI_BIN_KEYS_SCRATCH 4      //   bit 2 (mi3dgs_bin_tiles) = the caller does not read tile_keys back: the buffer is scratch (16-bit keys)
-#define MI_FLAG_PROBE 16          // project_bwd_adam: same code under another kernel name (placement search)
+
+// ---- experiments.  Everything that can return WRONG results (timing experiments) and every variant that was measured and
+// rejected lives behind -DMI3DGS_EXPERIMENTS (make exp -> libmi3dgs_exp.so, used by A/B tools and by the tests that
+// compare the product path against a rejected-but-correct variant).  The product library accepts none of those switches:
+// MI_EXPERIMENT_ENV() is a null pointer there, so the variable's NAME is not even in the binary
+// (tests/test_cabi_cpu.py: `strings libmi3dgs.so | grep MI3DGS_` = the documented tuning knobs of include/mi3dgs.h).
+#ifdef MI3DGS_EXPERIMENTS
+#include <stdlib.h>
+#define MI_EXPERIMENT_ENV(name) getenv(name)
+#else
+#define MI_EXPERIMENT_ENV(name) ((const char*)nullptr)
+#endif
 
 #define ALPHA_THRESHOLD (1.0f / 255.0f)
 #define MAX_ALPHA 0.999f

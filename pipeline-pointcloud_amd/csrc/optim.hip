@@ -37,8 +37,10 @@ constexpr int AD_PER_BLOCK = AD_THREADS * 4 * 4;   // 4 float4 per thread
 
 #define adam1 mi_adam1
 
+// gscale: every gradient is multiplied by it on the way in (the data-parallel trainer's 1 / world: its reduce-scatter
+// delivers the SUM over the ranks, and a separate mul_ pass over the slice was a read and a write of it per step)
 __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, float b2, float eps, float inv_bc1,
-                                                          float inv_bc2_sqrt) {
+                                                          float inv_bc2_sqrt, float gscale) {
     int blk = blockIdx.x;
     int s = 0;
 #pragma unroll
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, 
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float pe = p[it][e], me = m[it][e], ve = v[it][e];
-                adam1(pe, g[it][e], me, ve, step_size, b1, b2, inv_bc2_sqrt, eps);
+                adam1(pe, g[it][e] * gscale, me, ve, step_size, b1, b2, inv_bc2_sqrt, eps);
                 p[it][e] = pe; m[it][e] = me; v[it][e] = ve;
             }
             *reinterpret_cast<f32x4*>(sg.p + i) = p[it];     // parameters are re-read by the next forward
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_kernel(AdamArgs a, float b1, 
         if (i >= sg.n) break;
         for (int k = 0; k < 4 && i + k < sg.n; k++) {
             float p = sg.p[i + k], m = sg.m[i + k], v = sg.v[i + k];
-            adam1(p, sg.g[i + k], m, v, step_size, b1, b2, inv_bc2_sqrt, eps);
+            adam1(p, sg.g[i + k] * gscale, m, v, step_size, b1, b2, inv_bc2_sqrt, eps);
             sg.p[i + k] = p; sg.m[i + k] = m; sg.v[i + k] = v;
         }
     }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void scale_reg_kernel(int N, const float* __re
 // float segments.  `step` is the 1-based step count after increment.
 extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
                                 float* const* exp_avg_sq, const long long* numel, const float* lrs, int step,
-                                float beta1, float beta2, float eps, void* stream) {
+                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
     MI_REQUIRE(nseg >= 1 && nseg <= MI_ADAM_MAX_SEGS, "adam_step: 1..8 segments");
     MI_REQUIRE(step >= 1, "adam_step: step is 1-based");
     AdamArgs a;
@@ -144,7 +146,61 @@ extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* con
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     MI_LAUNCH("adam", adam_kernel, dim3(blocks), dim3(AD_THREADS), 0, (hipStream_t)stream, a, beta1, beta2, eps,
-                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- HBM yardstick.  What a plain 16-byte-per-lane stream gets from THIS device, measured by the bench itself
+// (bench.py: roofline.copy_GBps_this_box) instead of being assumed: NR arrays are read, their sum is written to NW arrays;
+// every array is `n4` float4 long and lives in `buf` one after the other (reads first).  (1, 1) is the float4 copy of
+// MI355X_MICROARCH.md (6.29 TB/s there); (5, 4) is the read : write mix of project_bwd_adam (1.78 : 1.45 GB).
+namespace {
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void hbm_stream_kernel(float4* __restrict__ buf, long long n4) {
+    constexpr int UN = 4;
+    const long long base = ((long long)blockIdx.x * UN) * 256 + threadIdx.x;
+    float4 acc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        float4 t[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = base + (long long)u * 256;
+            t[u] = buf[(long long)r * n4 + (i < n4 ? i : n4 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) { acc[u].x += t[u].x; acc[u].y += t[u].y; acc[u].z += t[u].z; acc[u].w += t[u].w; }
+    }
+    if (NW == 0) {          // read-only: keep the loads alive without storing anything that matters
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < UN; u++) s += acc[u].x + acc[u].y + acc[u].z + acc[u].w;
+        if (s == 1.2345e-30f) buf[0].x = s;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = base + (long long)u * 256;
+            if (i < n4) buf[(long long)(NR + w) * n4 + i] = acc[u];
+        }
+}
+}  // namespace
+
+extern "C" int mi3dgs_debug_hbm_stream(float* buf, long long floats_per_array, int n_read, int n_write, void* stream) {
+    MI_REQUIRE(buf && floats_per_array > 0 && (floats_per_array & 3) == 0 && (((uintptr_t)buf) & 15) == 0, "hbm_stream: bad buffer");
+    const long long n4 = floats_per_array / 4;
+    const dim3 grid((unsigned)mi_div_up(n4, 256 * 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    float4* b4 = reinterpret_cast<float4*>(buf);
+#define HS(R, W) else if (n_read == R && n_write == W) MI_LAUNCH("hbm_stream", (hbm_stream_kernel<R, W>), grid, block, 0, st, b4, n4)
+    if (false) {}
+    HS(1, 1); HS(2, 1); HS(5, 4); HS(1, 0); HS(0, 1); HS(4, 3);
+    else MI_REQUIRE(false, "hbm_stream: (n_read, n_write) must be one of (1,1) (2,1) (5,4) (4,3) (1,0) (0,1)");
+#undef HS
     MI_LAUNCH_CHECK();
     return 0;
 }

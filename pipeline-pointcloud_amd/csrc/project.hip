@@ -572,9 +572,13 @@ struct FusedAdam {
     float sreg_weight, sreg_max_ratio;   // scale regulariser of this step, weight 0 = off
 };
 
-// PROBE only gives the launches of the placement search (Trainer.tune_placement, MI3DGS_FLAG_PROBE)
-// a kernel name of their own, so that profiles keep them apart from the training steps.
-template <bool FUSE, bool PROBE = false>
+// (experiments build only: flags bit 6 / 7 skip the small groups' / the shN Adam -- timing experiments, WRONG results)
+#ifdef MI3DGS_EXPERIMENTS
+#define MI_BWD_SKIP(flags, bit) ((flags) & (bit))
+#else
+#define MI_BWD_SKIP(flags, bit) false
+#endif
+template <bool FUSE>
 __global__ __launch_bounds__(256) void project_bwd1_kernel(
     int N, float* means, float* quats, float* scales, float* opacities, float* shN, int sh_degree, FusedAdam A,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int W, int H, float eps2d, int flags,
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
             v_means[3 * n] = G.vmean[0]; v_means[3 * n + 1] = G.vmean[1]; v_means[3 * n + 2] = G.vmean[2];
             if (v_opacities) v_opacities[n] = G.vopa;
             v_sh0[3 * n] = vc0[0]; v_sh0[3 * n + 1] = vc0[1]; v_sh0[3 * n + 2] = vc0[2];
-        } else if (!(flags & 64)) {      // (flags bit 6 / 7: timing experiments only, skip the small groups' / the shN Adam)
+        } else if (!MI_BWD_SKIP(flags, 64)) {
             // ---- Adam on the five small groups, one thread per Gaussian
             float sl[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
             if (A.sreg_weight > 0.f) {
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     __builtin_amdgcn_wave_barrier();
     if (!FUSE) {
         slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
-    } else if (!(flags & 128)) {
+    } else if (!MI_BWD_SKIP(flags, 128)) {
         // ---- Adam on the wave's shN slice: gradients from LDS, p / m / v streamed with 16-byte accesses
         const long long off = 45 * (long long)n0;
         const int n4 = count >> 2;
@@ -988,7 +992,7 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
                                                      ((uintptr_t)v_quats)) & 15) == 0;
     if (fast) {
         FusedAdam none = {};
-        MI_LAUNCH("project_bwd", (project_bwd1_kernel<false, false>), dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+        MI_LAUNCH("project_bwd", (project_bwd1_kernel<false>), dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
                   const_cast<float*>(means), const_cast<float*>(quats), const_cast<float*>(scales),
                   const_cast<float*>(opacities), const_cast<float*>(shN), sh_degree, none, viewmats, Ks, width, height,
                   eps2d, flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN,
@@ -1030,14 +1034,8 @@ extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float*
     A.sh0 = sh0;
     A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
-    if (flags & MI_FLAG_PROBE)
-        MI_LAUNCH("project_bwd_adam/probe", (project_bwd1_kernel<true, true>), dim3(mi_div_up(N, 256)), dim3(256), 0,
-                  (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
-                  eps2d, flags, radii, splats, v_splats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,
-                  stat_count, stat_radii, stat_use_abs);
-    else
-        MI_LAUNCH("project_bwd_adam", (project_bwd1_kernel<true, false>), dim3(mi_div_up(N, 256)), dim3(256), 0,
-                  (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
+    MI_LAUNCH("project_bwd_adam", (project_bwd1_kernel<true>), dim3(mi_div_up(N, 256)), dim3(256), 0,
+              (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
                   eps2d, flags, radii, splats, v_splats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,
                   stat_count, stat_radii, stat_use_abs);
     MI_LAUNCH_CHECK();

@@ -1,7 +1,12 @@
-// Tile rasteriser, forward and backward.  gfx950 only.
+// C-ABI entry points of the tile rasteriser (mi3dgs_rasterize_fwd / mi3dgs_rasterize_bwd), and -- in the EXPERIMENTS build
+// only -- the round-1 VALU kernels they used to launch.  gfx950 only.
 //
 // Replaces gsplat rasterize_to_pixels_{fwd,bwd}, reached by the
 // reference only through main.py:1312 / main.py:1343.
+//
+// The product kernels are rasterize_mfma.hip (forward) and rasterize_bwd_mm.hip (backward).  What follows under
+// MI3DGS_EXPERIMENTS is the first correct path of round 1, kept for same-box A/B measurements
+// (libmi3dgs_exp.so, mi3dgs_debug_set_raster_mode(0)):
 //
 // One 256-thread workgroup per 16x16 tile = 4 wave64s, each wave owning an 8x8 pixel
 // quadrant (tighter screen footprint per wave => more wave-uniform skips than a 16x4 strip).
@@ -13,11 +18,12 @@
 // flushed with lanes mapped (record, dword) so that each (tile, Gaussian) costs ONE 64-byte
 // float-atomic request into the packed gradient record (MI355X_MICROARCH "Global float
 // atomics": requests, not bytes, are the unit that is rate-limited).
-//
-// Bound: VALU/LDS (about 20 flop fwd, 60 flop bwd per pixel-splat pair); HBM traffic is
-// I*64 B gather + Px*20 B fwd, I*64 B gather + I*64 B atomics + Px*36 B bwd.
 #include "common.h"
 
+constexpr int TILE = 16;
+[[maybe_unused]] constexpr int BLOCK = TILE * TILE;
+
+#ifdef MI3DGS_EXPERIMENTS
 #ifdef MI_RASTER_STATS
 // debug build only (make STATS=1): [0] (wave,splat) visits, [1] visits with >=1 live lane,
 // [2] live lanes, [3] slots flushed with atomics, [4] slots staged
@@ -30,9 +36,6 @@ extern "C" int mi3dgs_debug_raster_stats(unsigned long long* host_out, int reset
 #endif
 
 namespace {
-
-constexpr int TILE = 16;
-constexpr int BLOCK = TILE * TILE;
 
 __device__ __forceinline__ void pixel_of_thread(int tid, int& lx, int& ly) {
     int w = tid >> 6, l = tid & 63;
@@ -312,24 +315,30 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 
 }  // namespace
 
-// the MFMA rasterisers (rasterize_mfma.hip) are the product path; the round-1 VALU kernels above stay
-// selectable for same-box A/B measurements (mi3dgs_debug_set_raster_mode(0)); forward and backward must
-// run in the same mode (they decide alpha >= 1/255 with the same arithmetic only within a mode)
+#endif  // MI3DGS_EXPERIMENTS
+
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
-                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, int prefetch, hipStream_t st);
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st);
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
                           const float* v_alphas, int absgrad, float* v_splats, int variant, hipStream_t st);
 static int g_raster_mode = 1;
+// Mode 1 = the product kernels, the only mode the product library has.  The experiments build (libmi3dgs_exp.so) adds:
+// 0 = round-1 VALU kernels; 3 = MFMA forward + backward with the all-f32 cross-lane reduce-scatter instead of the bf16 MFMA
+// contraction (correct; the f32 yardstick of tests/test_gpu_configs.py); 4 = backward with THREE-term bf16 pixel sums
+// (24 significant bits; the A/B of VERDICT r2 #3); 14 = wave-flush backward (correct, slower); 11..13 = timing experiments
+// with WRONG results (no group flush / constant colours).  Forward and backward must run in the same mode.
 extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
-    // 0 = round-1 VALU kernels, 1 = MFMA (default), 2 = A/B variants that were measured slower on the same box and stay off:
-    // forward with the next sub-batch's MFMAs issued before the current one is composited (137 -> 173 us: 96 instead of 64
-    // VGPRs), backward with the tile list fetched one batch ahead (no change; in the forward 136.6 -> 149.5 us),
-    // 3 = MFMA forward, backward with the cross-lane reduce-scatter instead of the MFMA contraction
-    g_raster_mode = (mode < 0 || (mode > 3 && (mode < 11 || mode > 14))) ? 1 : mode;     // 11..13: timing experiments, 14: wave-flush variant
+#ifdef MI3DGS_EXPERIMENTS
+    MI_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 4 || (mode >= 11 && mode <= 14), "set_raster_mode: unknown mode");
+    g_raster_mode = mode;
     return 0;
+#else
+    MI_REQUIRE(mode == 1, "set_raster_mode: this is the product library, it has mode 1 only (experiments: libmi3dgs_exp.so)");
+    return 0;
+#endif
 }
 
 extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
@@ -342,19 +351,22 @@ extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size,
                "rasterize_fwd: tile grid does not match image size");
     int n_tiles = C * tile_width * tile_height;
     hipStream_t st = (hipStream_t)stream;
-    if (g_raster_mode != 0)
-        return mi_rasterize_fwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
-                                     n_isect_dev, backgrounds, render, alphas, last_ids, g_raster_mode == 2, st);
-    if (backgrounds)
-        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
-                           tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
-                           alphas, last_ids);
-    else
-        MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
-                           tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
-                           alphas, last_ids);
-    MI_LAUNCH_CHECK();
-    return 0;
+#ifdef MI3DGS_EXPERIMENTS
+    if (g_raster_mode == 0) {
+        if (backgrounds)
+            MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<true>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
+                               alphas, last_ids);
+        else
+            MI_LAUNCH("rasterize_fwd", rasterize_fwd_kernel<false>, dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,
+                               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render,
+                               alphas, last_ids);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    return mi_rasterize_fwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
+                                 n_isect_dev, backgrounds, render, alphas, last_ids, st);
 }
 
 extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
@@ -367,17 +379,19 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
                "rasterize_bwd: tile grid does not match image size");
     int n_tiles = C * tile_width * tile_height;
     hipStream_t st = (hipStream_t)stream;
-    if (g_raster_mode != 0)
-        return mi_rasterize_bwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
-                                     n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats,
-                                     g_raster_mode == 1 ? 0 : g_raster_mode >= 10 ? g_raster_mode : g_raster_mode == 2 ? 2 : 1, st);
+#ifdef MI3DGS_EXPERIMENTS
+    if (g_raster_mode == 0) {
 #define LAUNCH_BWD(BG, AG)                                                                                            \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,   \
                        tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas,     \
                        last_ids, v_render, v_alphas, v_splats)
-    if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
-    else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
+        if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
+        else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
 #undef LAUNCH_BWD
-    MI_LAUNCH_CHECK();
-    return 0;
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    return mi_rasterize_bwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
+                                 n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, g_raster_mode, st);
 }

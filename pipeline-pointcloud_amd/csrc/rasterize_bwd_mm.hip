@@ -435,8 +435,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
 
 }  // namespace mfma_raster
 
-// experiment: 0 = the product kernel; timing experiments with WRONG results, kept for the measurements quoted in DESIGN.md:
-// bit 0 no group barriers / flush, bit 1 no colour reads (only without background and absgrad)
+// experiment: 0 = the product kernel, the only one the product library holds.  Experiments build (libmi3dgs_exp.so):
+// 14 = the wave-flush variant (correct); 11..13 = timing experiments with WRONG results, kept for the measurements quoted in
+// DESIGN.md (bit 0 no group barriers / flush, bit 1 no colour reads; only without background and absgrad)
 int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
@@ -446,14 +447,23 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
-    if (experiment == 4) {           // wave-flush variant (correct results)
+#ifdef MI3DGS_EXPERIMENTS
+    if (experiment == 14) {           // wave-flush variant (correct results)
         if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4); else LAUNCH_MM(true, false, 4); }
         else { if (absgrad) LAUNCH_MM(false, true, 4); else LAUNCH_MM(false, false, 4); }
-    } else if (experiment != 0 && !backgrounds && !absgrad) {
-        if (experiment == 1) LAUNCH_MM(false, false, 1);
-        else if (experiment == 2) LAUNCH_MM(false, false, 2);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+    if (experiment >= 11 && experiment <= 13 && !backgrounds && !absgrad) {
+        if (experiment == 11) LAUNCH_MM(false, false, 1);
+        else if (experiment == 12) LAUNCH_MM(false, false, 2);
         else LAUNCH_MM(false, false, 3);
-    } else if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0); else LAUNCH_MM(true, false, 0); }
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    MI_REQUIRE(experiment == 0, "rasterize_bwd: unknown variant");
+    if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0); else LAUNCH_MM(true, false, 0); }
     else { if (absgrad) LAUNCH_MM(false, true, 0); else LAUNCH_MM(false, false, 0); }
 #undef LAUNCH_MM
     MI_LAUNCH_CHECK();

@@ -227,7 +227,7 @@ __device__ __forceinline__ int tile_of_block(int b, int n_tiles, int bands, int 
     return (tx < tw && t < n_tiles) ? t : -1;
 }
 inline int raster_bands() {
-    static const int v = [] { const char* e = getenv("MI3DGS_XCD_BANDS"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_XCD_BANDS"); return e ? atoi(e) : 0; }();       // (experiments build only: both measured slower)
     return v;
 }
 // blocks to launch for n_tiles tiles of a tw-wide tile grid

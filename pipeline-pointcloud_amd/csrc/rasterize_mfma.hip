@@ -109,6 +109,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     }
 }
 
+#ifdef MI3DGS_EXPERIMENTS
 // ---------------------------------------------------------------------------------------- backward (cross-lane reduce-scatter)
 struct StagedBwd {
     Staged f;
@@ -314,16 +315,17 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 }
 
 
+#endif  // MI3DGS_EXPERIMENTS
+
 }  // namespace mfma_raster
 
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
-                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, int prefetch, hipStream_t st) {
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st) {
     using namespace mfma_raster;
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands())
-    (void)prefetch;      // (a variant with the next sub-batch's MFMAs issued early was measured slower and is gone)
     if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
 #undef LAUNCH_FWD
     MI_LAUNCH_CHECK();
@@ -338,23 +340,24 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int variant, hipStream_t st) {
+                          const float* v_alphas, int absgrad, float* v_splats, int mode, hipStream_t st) {
     using namespace mfma_raster;
-    // variant 0 and 10 + e: the contraction on the matrix pipe (rasterize_bwd_mm.hip, the product path); 1: cross-lane
-    // reduce-scatter (this file), 2: that with the tile list fetched one batch ahead
-    if (variant == 0 || variant >= 10)
-        return mi_rasterize_bwd_mm(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids, n_isect_dev,
-                                   backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, variant >= 10 ? variant - 10 : 0, st);
-    const int prefetch = variant == 2;
-#define LAUNCH_BWD(BG, AG, PF)                                                                                             \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, PF>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
+    // mode 1: the contraction on the matrix pipe (rasterize_bwd_mm.hip), the product path and the only one of the product
+    // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 and 11..14 = variants of the product
+    // kernel (rasterize_bwd_mm.hip: 4 three-term sums, 14 wave flush, 11..13 timing experiments with wrong results)
+#ifdef MI3DGS_EXPERIMENTS
+    if (mode == 3) {
+#define LAUNCH_BWD(BG, AG)                                                                                                 \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, false>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
-#define LAUNCH_BWD2(BG, AG) do { if (prefetch) LAUNCH_BWD(BG, AG, true); else LAUNCH_BWD(BG, AG, false); } while (0)
-    if (backgrounds) { if (absgrad) LAUNCH_BWD2(true, true); else LAUNCH_BWD2(true, false); }
-    else { if (absgrad) LAUNCH_BWD2(false, true); else LAUNCH_BWD2(false, false); }
-#undef LAUNCH_BWD2
+        if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
+        else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
 #undef LAUNCH_BWD
-    MI_LAUNCH_CHECK();
-    return 0;
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
+    return mi_rasterize_bwd_mm(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids, n_isect_dev,
+                               backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, mode == 1 ? 0 : mode, st);
 }

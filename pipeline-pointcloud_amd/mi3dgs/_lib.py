@@ -10,11 +10,17 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MI3DGS_LIB: another build of the same ABI, for same-box A/B measurements of two versions of a kernel
+# MI3DGS_LIB: another build of the same ABI, for same-box A/B measurements of two versions of a kernel (announced on
+# stderr when it is used: a leaked variable must not silently swap the library under a training job)
 LIB_PATH = os.environ.get("MI3DGS_LIB") or os.path.join(_HERE, "libmi3dgs.so")
+# the EXPERIMENTS build (rejected variants, timing experiments with wrong results): never loaded by the product path,
+# only by experiments_lib() -- the A/B tools under tools/ and the tests that use a rejected-but-correct variant as a yardstick
+EXP_LIB_PATH = os.path.join(_HERE, "libmi3dgs_exp.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+ABI_VERSION = 4
 
 _lib: Optional[C.CDLL] = None
+_exp_lib: Optional[C.CDLL] = None
 
 _f = C.c_void_p      # device pointers travel as void*
 _i = C.c_int
@@ -55,7 +61,8 @@ _SIGNATURES = {
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_scale_reg": (_i, [_i, _f, _fl, _fl, _f, _f, _f]),
     "mi3dgs_adam_step": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_ll),
-                              C.POINTER(_fl), _i, _fl, _fl, _fl, _f]),
+                              C.POINTER(_fl), _i, _fl, _fl, _fl, _fl, _f]),
+    "mi3dgs_debug_hbm_stream": (_i, [_f, _ll, _i, _i, _f]),
     "mi3dgs_densify_decide": (_i, [_i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f]),
     "mi3dgs_densify_scatter": (_i, [_i, _ll, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
                                     C.POINTER(_f), _f, _f, _ll, _u32, _f, _f]),
@@ -78,6 +85,17 @@ class Mi3dgsError(RuntimeError):
     pass
 
 
+def _open(path: str) -> C.CDLL:
+    handle = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)     # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if handle.mi3dgs_abi_version() != ABI_VERSION:
+        raise Mi3dgsError(f"{path}: ABI version mismatch")
+    return handle
+
+
 def lib() -> C.CDLL:
     """Load the library (once).  Raises if it has not been built: there is no CPU path."""
     global _lib
@@ -86,20 +104,30 @@ def lib() -> C.CDLL:
             raise Mi3dgsError(
                 f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` "
                 "(or __graft_entry__.build()).  mi3dgs has no fallback path.")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(handle, name)     # AttributeError here = header and library disagree
-            fn.restype = res
-            fn.argtypes = args
-        if handle.mi3dgs_abi_version() != 3:
-            raise Mi3dgsError("libmi3dgs.so ABI version mismatch")
-        # A/B switches for measurements (defaults are the product path): MI3DGS_EMIT_MODE, MI3DGS_RASTER_MODE, MI3DGS_SORT_MODE
-        for env, fn in (("MI3DGS_EMIT_MODE", "mi3dgs_debug_set_emit_mode"), ("MI3DGS_RASTER_MODE", "mi3dgs_debug_set_raster_mode"),
-                        ("MI3DGS_SORT_MODE", "mi3dgs_debug_set_sort_mode")):
-            if os.environ.get(env) is not None:
-                getattr(handle, fn)(int(os.environ[env]))
-        _lib = handle
+        if os.environ.get("MI3DGS_LIB"):
+            import sys
+            print(f"[mi3dgs] WARNING: MI3DGS_LIB is set, loading {LIB_PATH} instead of the product library", file=sys.stderr, flush=True)
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+def experiments_lib() -> C.CDLL:
+    """The -DMI3DGS_EXPERIMENTS build of the same sources (A/B tools, yardstick tests).  Its own globals, its own device
+    error word; calls go through `exp_call`."""
+    global _exp_lib
+    if _exp_lib is None:
+        if not os.path.isfile(EXP_LIB_PATH):
+            raise Mi3dgsError(f"{EXP_LIB_PATH} not found: build it with `make -C {CSRC_DIR}`")
+        _exp_lib = _open(EXP_LIB_PATH)
+    return _exp_lib
+
+
+def exp_call(name: str, *args) -> None:
+    h = experiments_lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        msg = h.mi3dgs_last_error()
+        raise Mi3dgsError(msg.decode() if msg else f"mi3dgs (experiments) call failed with code {rc}")
 
 
 def check(rc: int) -> None:

@@ -70,6 +70,10 @@ def parse_ns_train(argv: List[str]) -> Dict:
     out["max_steps"] = int(float(o.get("--max-num-iterations", "30000")))
     out["timestamp"] = o.get("--timestamp", time.strftime("%Y-%m-%d_%H%M%S"))
     out["scale_reg"] = str(o.get("--pipeline.model.use_scale_regularization", "False")).lower() == "true"
+    # nerfstudio's names for the MCMC knobs of splatfacto-mcmc (SplatfactoModelConfig)
+    out["mcmc"] = {k2: float(o[k1]) for k1, k2 in (("--pipeline.model.mcmc-opacity-reg", "opacity_reg"),
+                                                   ("--pipeline.model.mcmc-scale-reg", "scale_reg"),
+                                                   ("--pipeline.model.noise-lr", "noise_lr")) if k1 in o}
     return out
 
 
@@ -98,7 +102,11 @@ def parse_simple_trainer(argv: List[str]) -> Dict:
                max_steps=int(float(kv.get("max_steps", 30000))), data_factor=int(float(kv.get("data_factor", 1))),
                steps_scaler=float(kv.get("steps_scaler", 1.0)), batch_size=int(float(kv.get("batch_size", 1))),
                antialiased=bool(kv.get("antialiased", False)), random_bkgd=bool(kv.get("random_bkgd", False)),
-               absgrad=bool(kv.get("absgrad", False)), max_gaussians=int(float(kv.get("max_gaussians", 8_000_000))))
+               absgrad=bool(kv.get("absgrad", False)), max_gaussians=int(float(kv.get("max_gaussians", 8_000_000))),
+               # gsplat's own names for the MCMC knobs (Config.opacity_reg / scale_reg, MCMCStrategy.noise_lr / min_opacity)
+               mcmc={k2: float(kv[k1]) for k1, k2 in (("opacity_reg", "opacity_reg"), ("scale_reg", "scale_reg"),
+                                                      ("strategy.noise_lr", "noise_lr"), ("strategy.min_opacity", "min_opacity"))
+                     if k1 in kv})
     if not out["data_dir"]:
         raise SystemExit("simple_trainer.py: --data-dir is required")
     return out
@@ -159,7 +167,7 @@ class ViewOrder:
 
 def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int = 100, save_steps=(),
                  on_save=None, strategy: str = "default", cap_max: int = 1_000_000, init_opacity: float = 0.1,
-                 init_scale: float = 1.0, frame: str = "nerfstudio") -> Tuple[object, object, Dict]:
+                 init_scale: float = 1.0, frame: str = "nerfstudio", mcmc_overrides: Optional[Dict] = None) -> Tuple[object, object, Dict]:
     """Loads the dataset, trains, evaluates.  Returns (trainer, dataset, stats)."""
     from . import dataset as ds_mod
     from . import parallel
@@ -180,7 +188,7 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     vm, ks = ds.viewmats[ds.train_idx].to(dev), ds.Ks[ds.train_idx].to(dev)
     if strategy == "mcmc":
         from .strategy_mcmc import MCMCConfig, MCMCTrainer
-        mc = MCMCConfig(cap_max=cap_max, refine_stop_iter=max(1, int(cfg.max_steps * 25 / 30)))
+        mc = MCMCConfig(cap_max=cap_max, refine_stop_iter=max(1, int(cfg.max_steps * 25 / 30)), **(mcmc_overrides or {}))
         if ctx is not None and ctx.active:
             tr = parallel.make_mcmc_data_parallel()(params, vm, ks, imgs, ds.width, ds.height, cfg, mc, ctx=ctx)
         else:
@@ -189,8 +197,8 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
         cls = parallel.DataParallelTrainer if (ctx is not None and ctx.active) else Trainer
         kw = {"ctx": ctx} if cls is parallel.DataParallelTrainer else {}
         tr = cls(params, vm, ks, imgs, ds.width, ds.height, cfg, **kw)
-    if os.environ.get("MI3DGS_TUNE_PLACEMENT"):
-        tr.tune_placement(log=say if (ctx is None or ctx.rank == 0) else None)
+    if ctx is None or ctx.rank == 0:
+        tr.log = say
     say(f"loaded in {time.time() - t0:.1f}s; training {cfg.max_steps} steps from {tr.model.n} Gaussians "
         f"(capacity {tr.model.capacity})")
     V = len(ds.train_idx)
@@ -229,7 +237,8 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     torch.cuda.synchronize()
     tr.check_async_errors()                # chained kernels that gave up / truncated tile lists since the last refine
     train_s = time.time() - t_train
-    stats = dict(train_seconds=train_s, iters_per_sec=cfg.max_steps / max(train_s, 1e-9), gaussians=tr.model.n)
+    stats = dict(train_seconds=train_s, iters_per_sec=cfg.max_steps / max(train_s, 1e-9), gaussians=tr.model.n,
+                 isect_overflows=tr.isect_overflows)
     if ds.eval_idx and rank == 0:
         ev = ds.load_images(ds.eval_idx, dev)
         ps = []
@@ -273,7 +282,7 @@ def main_ns_train(argv: Optional[List[str]] = None) -> int:
     cap = int(float(a["opts"].get("--max-gaussians", 1_000_000 if mcmc else 8_000_000)))   # splatfacto-mcmc max_gs_num 1e6
     tr, ds, stats = run_training(a["data"], a["downscale"], lambda ds: splatfacto_config(
         a["model"], a["max_steps"], a["scale_reg"], max(1, len(ds.train_idx)), cap),
-        strategy="mcmc" if mcmc else "default", cap_max=cap)
+        strategy="mcmc" if mcmc else "default", cap_max=cap, mcmc_overrides=a.get("mcmc"))
     cfg = tr.cfg
     out_dir = os.path.join("outputs", "unnamed", "splatfacto", a["timestamp"])       # the path main.py:2158 copies from
     os.makedirs(os.path.join(out_dir, "nerfstudio_models"), exist_ok=True)
@@ -352,7 +361,7 @@ def _simple_trainer_rank(rank: int, world: int, port: int, a: Dict) -> None:
                                  cap_max=min(a["max_gaussians"], 1_000_000) if a["strategy"] == "mcmc" else a["max_gaussians"],
                                  # gsplat's `mcmc` preset: init_opa 0.5, init_scale 0.1 [UPSTREAM-UNVERIFIED]
                                  init_opacity=0.5 if a["strategy"] == "mcmc" else 0.1,
-                                 init_scale=0.1 if a["strategy"] == "mcmc" else 1.0)
+                                 init_scale=0.1 if a["strategy"] == "mcmc" else 1.0, mcmc_overrides=a.get("mcmc"))
     cfg = tr.cfg
     save(tr, ds, cfg.max_steps - 1)            # every rank holds the full (replicated) model
     # The reference's exporter converts sorted(os.listdir(ckpts))[-1] (gsplat_pt_to_ply.py:36-40), a

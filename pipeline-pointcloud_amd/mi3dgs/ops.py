@@ -21,7 +21,6 @@ GRAD_STRIDE = 16
 FLAG_LOG_SCALES = 1
 FLAG_LOGIT_OPAC = 2
 FLAG_ANTIALIASED = 4
-FLAG_PROBE = 16
 COLOR_SH, COLOR_PER_GAUSSIAN, COLOR_PER_CAMERA = 0, 1, 2
 
 
@@ -287,7 +286,7 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
 
 
 def adam_step(params: Sequence[torch.Tensor], grads, exp_avg, exp_avg_sq, lrs: Sequence[float], step: int,
-              beta1=0.9, beta2=0.999, eps=1e-15, numel: Optional[Sequence[int]] = None):
+              beta1=0.9, beta2=0.999, eps=1e-15, numel: Optional[Sequence[int]] = None, grad_scale: float = 1.0):
     n = len(params)
     for i in range(n):
         for t, nm in ((params[i], "param"), (grads[i], "grad"), (exp_avg[i], "exp_avg"), (exp_avg_sq[i], "exp_avg_sq")):
@@ -295,7 +294,7 @@ def adam_step(params: Sequence[torch.Tensor], grads, exp_avg, exp_avg_sq, lrs: S
     ne = (C.c_longlong * n)(*[int(numel[i]) if numel is not None else params[i].numel() for i in range(n)])
     lr = (C.c_float * n)(*[float(x) for x in lrs])
     _lib.call("mi3dgs_adam_step", n, _ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg),
-              _ptr_array(exp_avg_sq), ne, lr, int(step), float(beta1), float(beta2), float(eps),
+              _ptr_array(exp_avg_sq), ne, lr, int(step), float(beta1), float(beta2), float(eps), float(grad_scale),
               _stream(params[0].device))
 
 

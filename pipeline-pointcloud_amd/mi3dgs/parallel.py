@@ -198,11 +198,12 @@ class DataParallelMixin:
         if pieces:
             lrs = self.lrs()
             P, M, V = m.flat["p"][m.cur], m.flat["m"][m.cur], m.flat["v"][m.cur]
-            inv = 1.0 / self.ctx.world
-            gs = [gflat[a: a + cnt].mul_(inv) for _, a, cnt in pieces]
+            # the reduce-scatter delivered the SUM over the ranks; the mean's 1 / world is applied by the Adam kernel as it
+            # reads the gradient (a separate mul_ over the slice was one more read and write of it per step)
+            gs = [gflat[a: a + cnt] for _, a, cnt in pieces]
             ops.adam_step([P[a: a + cnt] for _, a, cnt in pieces], gs, [M[a: a + cnt] for _, a, cnt in pieces],
                           [V[a: a + cnt] for _, a, cnt in pieces], [lrs[gi] for gi, _, _ in pieces], self.step_count + 1,
-                          beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps)
+                          beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps, grad_scale=1.0 / self.ctx.world)
         all_gather_slices_(m.flat["p"][m.cur], self.ctx)
         self._moments_current = False
 

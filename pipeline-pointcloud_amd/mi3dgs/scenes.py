@@ -139,5 +139,31 @@ def make_6m(n: int = 6_000_000, seed: int = 3, **kw) -> Scene:
     return make_garden_like(n=n, seed=seed, ground_radius=20.0, cam_radius=5.0, name="S3-6M", **kw)
 
 
+def add_backdrop(sc: Scene, n: int, radius: float, centre=(0.0, 0.0, 0.0), seed: int = 11) -> Scene:
+    """The scene inside an opaque shell of `n` Gaussians of radius `radius` around `centre`, smoothly coloured by direction:
+    every pixel of every view then shows scene content, as in a photograph.  (The end-to-end training datasets need it: RGB
+    targets whose uncovered pixels carry a constant background colour can only be fitted by a fog of huge transparent
+    Gaussians -- not a thing a trainer should be validated on; tools/train_synthetic.py, tools/train_wolf.py.)"""
+    g = torch.Generator().manual_seed(seed)
+    i = torch.arange(n, dtype=torch.float64) + 0.5
+    phi = torch.acos(1.0 - 2.0 * i / n)                       # Fibonacci sphere: even spacing
+    th = math.pi * (1.0 + 5.0 ** 0.5) * i
+    d = torch.stack([torch.sin(phi) * torch.cos(th), torch.sin(phi) * torch.sin(th), torch.cos(phi)], dim=-1).float()
+    means = torch.tensor(centre, dtype=torch.float32) + radius * d
+    spacing = radius * math.sqrt(4.0 * math.pi / n)
+    ls = torch.full((n, 3), math.log(0.8 * spacing))
+    quats = torch.zeros(n, 4)
+    quats[:, 0] = 1.0
+    # low-frequency colour pattern in [0.15, 0.85], as SH DC:  rgb = 0.5 + 0.2821 * sh0
+    rgb = 0.5 + 0.35 * torch.stack([torch.sin(3.0 * d[:, 0] + 1.0) * torch.cos(2.0 * d[:, 1]),
+                                    torch.sin(2.0 * d[:, 1] + 2.0) * torch.cos(3.0 * d[:, 2]),
+                                    torch.sin(4.0 * d[:, 2]) * torch.cos(2.0 * d[:, 0] + 0.5)], dim=-1)
+    rgb = rgb + 0.03 * torch.randn(n, 3, generator=g)
+    B = dict(means=means, quats=quats, scales=ls, opacities=torch.full((n,), 4.0), sh0=((rgb - 0.5) / 0.28209479)[:, None, :],
+             shN=torch.zeros(n, 15, 3))
+    P = {k: torch.cat([sc.params[k], B[k].to(sc.params[k].dtype)], dim=0).contiguous() for k in sc.params}
+    return Scene(sc.name + "+backdrop", P, sc.viewmats, sc.Ks, sc.width, sc.height, sc.sh_degree)
+
+
 def make_scene(kind: str, **kw) -> Scene:
     return {"cube": make_cube, "lego": make_lego_like, "garden": make_garden_like, "6m": make_6m}[kind](**kw)

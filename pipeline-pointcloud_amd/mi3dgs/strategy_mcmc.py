@@ -23,6 +23,7 @@ from .trainer import GROUPS, TrainConfig, Trainer
 
 N_MAX = 51
 _NAN_CHECK = bool(__import__("os").environ.get("MI3DGS_NAN_CHECK"))
+_REFINE_LOG = bool(__import__("os").environ.get("MI3DGS_MCMC_LOG"))      # one line per refine: dead fraction, opacity, ratios
 
 
 @dataclasses.dataclass
@@ -66,6 +67,7 @@ class MCMCTrainer(Trainer):
         self.binoms = binom_table(self.device)
         self.tgen = torch.Generator(device=self.device).manual_seed(cfg.seed + 77)
         self.mcmc_totals = dict(relocated=0, added=0)
+        self.last_max_ratio = 0
 
     # gradients of the two regularisers, between the backward and Adam
     def _grad_hooks(self):
@@ -90,8 +92,17 @@ class MCMCTrainer(Trainer):
                       f"\n   prev m/v means {self._prev_mv['means'][0][i].tolist()} {self._prev_mv['means'][1][i].tolist()} viewmat {self.viewmats[view_index].tolist()}", flush=True)
         c, m = self.mcmc, self.model
         if c.refine_start_iter < step < c.refine_stop_iter and step % c.refine_every == 0:
-            self.mcmc_totals["relocated"] += self.relocate()
-            self.mcmc_totals["added"] += self.add_new()
+            n_rel = self.relocate()
+            n_add = self.add_new()
+            self.mcmc_totals["relocated"] += n_rel
+            self.mcmc_totals["added"] += n_add
+            if _REFINE_LOG and (step % (10 * c.refine_every) == 0 or n_rel > 0.2 * m.n):
+                op = torch.sigmoid(self._rows("opacities")[: m.n, 0])
+                q = torch.quantile(op[:1_000_000], torch.tensor([0.1, 0.5, 0.9], device=op.device)).tolist()
+                sc = self._rows("scales")[: m.n].exp().amax(-1)
+                print(f"[mcmc] step {step} n={m.n} relocated={n_rel} ({100.0 * n_rel / max(m.n, 1):.1f} %) added={n_add} "
+                      f"max_ratio={self.last_max_ratio} opacity q10/50/90 {q[0]:.4f}/{q[1]:.4f}/{q[2]:.4f} mean {float(op.mean()):.4f} "
+                      f"max-scale median {float(sc.median()):.5f} max {float(sc.max()):.4f}", flush=True)
         seed = (self.cfg.seed * 2654435761 + step * 40503 + 17) & 0xFFFFFFFF
         lr_means = self.lrs()[0]
         ops._lib.call("mi3dgs_mcmc_inject_noise", m.n, ops._p(m.p("means")), ops._p(m.p("quats")), ops._p(m.p("scales")),
@@ -121,6 +132,8 @@ class MCMCTrainer(Trainer):
         op = torch.sigmoid(self._rows("opacities")[sampled, 0])
         sc = torch.exp(self._rows("scales")[sampled])
         counts = torch.bincount(sampled, minlength=m.n)[sampled] + 1
+        if _REFINE_LOG and zero_source_state:
+            self.last_max_ratio = int(counts.max())               # of the relocation (the growth step's ratios are 1-2)
         no, ns = compute_relocation(op, sc, counts.clamp(max=N_MAX), self.binoms)
         # (the alternating binomial sum of the scale formula cancels in float32 for large ratios: keep the old scale rather than
         #  the logarithm of a non-positive number)

@@ -20,7 +20,6 @@ import torch
 from . import ops
 
 GROUPS = ("means", "quats", "scales", "opacities", "sh0", "shN")
-_EXPERIMENT_FLAGS = int(__import__("os").environ.get("MI3DGS_BWD_EXPERIMENT", "0"))     # timing experiments of project_bwd_adam (wrong results)
 WIDTHS = (3, 4, 3, 1, 3, 45)
 _SHAPES = {"means": (3,), "quats": (4,), "scales": (3,), "opacities": (), "sh0": (1, 3), "shN": (15, 3)}
 
@@ -158,6 +157,10 @@ class Trainer:
         self.W, self.H = int(width), int(height)
         self.W0, self.H0, self.Ks0, self._cur_d = self.W, self.H, self.Ks, 1
         self._auto_cap: Optional[int] = None       # auto_isect_capacity: current capacity, None = measure first
+        self._auto_caps: Dict[int, int] = {}       # ... per resolution divisor: a render() at full size must not cost the training
+        self._auto_cap_n: Dict[int, int] = {}      #     resolution its calibration (and the Gaussian count it was made at)
+        self._last_cap_check_step = 0
+        self.log = None                            # callable(str): where absorbed capacity overflows are reported (cli: rank 0)
         self._isect_peak = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.isect_overflows = 0
         self.step_count = 0
@@ -186,8 +189,8 @@ class Trainer:
         """Keyword arguments for GaussianModel (the sharded data-parallel trainer asks for flat buffers)."""
         # One allocation per kind (parameters, exp_avg, exp_avg_sq, gradients) instead of eighteen: the fused backward +
         # Adam kernel streams all of them at once and its speed depends on where their pages landed (DESIGN.md,
-        # "placement").  With separate allocations it ran 588-589 us without the start-up search, flat 548-575 us on the
-        # same box (gpurun_out/r2k, tools/placement_ab.sh); the search (Trainer.tune_placement) is now opt-in.
+        # "placement": 18 separate arrays 588-589 us, flat 548-575 us on the same box, profiles/r02_placement_ab.txt,
+        # measured with the round-2 switch MI3DGS_FLAT_MODEL).  It is also what the sharded optimiser exchanges.
         import os
         return {} if os.environ.get("MI3DGS_SEPARATE_ARRAYS") else dict(flat=True)
 
@@ -198,7 +201,7 @@ class Trainer:
         f = ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC
         if self.cfg.antialiased:
             f |= ops.FLAG_ANTIALIASED
-        return f | _EXPERIMENT_FLAGS
+        return f
 
     def downscale_now(self) -> int:
         c = self.cfg
@@ -211,8 +214,12 @@ class Trainer:
         d = max(1, int(d))
         if d == self._cur_d:
             return
+        if self._auto_cap is not None:        # intersection counts scale with the tile grid: one calibrated capacity per level
+            self._auto_caps[self._cur_d], self._auto_cap_n[self._cur_d] = self._auto_cap, self.model.n
         self._cur_d = d
-        self._auto_cap = None                 # intersection counts scale with the tile grid: measure again
+        self._auto_cap = None
+        if d in self._auto_caps:              # back at a level seen before: its capacity, scaled by the growth in Gaussians since
+            self._auto_cap = int(self._auto_caps[d] * max(1.0, self.model.n / max(self._auto_cap_n.get(d, self.model.n), 1))) + (1 << 16)
         self.W, self.H = max(1, self.W0 // d), max(1, self.H0 // d)
         self.Ks = self.Ks0.clone()
         self.Ks[:, :2, :] /= float(d)
@@ -324,137 +331,6 @@ class Trainer:
             return float(ops.loss_value(sums, self.H * self.W * 3, c.ssim_lambda))
         return None
 
-    # -- HBM placement of the parameter / moment arrays ------------------------------------
-    @torch.no_grad()
-    def tune_placement(self, sweeps: int = 24, min_gain: float = 0.003, budget_s: float = 3.0, min_gaussians: int = 200_000,
-                       log=None) -> Dict[str, float]:
-        """The fused backward+Adam kernel streams 18 arrays (6 groups x parameter / exp_avg /
-        exp_avg_sq) at once, and its speed depends on which physical pages each of them got: 576 to
-        677 us on identical code and addresses ("placement").  This walks the arrays of
-        both banks, gives each a few alternative allocations, times the kernel itself on every
-        candidate and keeps the best.  The kernel runs as an exact no-op while it is timed (zero
-        gradients, zero moments, zero learning rates), so it must be called before the first step.
-        Costs a few hundred milliseconds and, transiently, a few GB."""
-        c, m = self.cfg, self.model
-        if not (c.fuse_adam and self._can_fuse_adam()) or self.step_count != 0:
-            return {}
-        if m.flat is not None:                  # the search re-allocates single arrays; the flat layout has none
-            if log is not None:
-                log("placement: flat model layout, nothing to tune (MI3DGS_SEPARATE_ARRAYS=1 restores the round-1 layout)")
-            return {}
-        if m.n < min_gaussians:                  # the kernel is launch-bound down here; nothing to gain
-            return {}
-        n = m.n
-        viewmat, K = self.viewmats[:1], self.Ks[:1]
-        sd = c.sh_degree
-        self._forward(viewmat, K, sd)                        # fills self.radii / self.splats for one real view
-        self.v_splats.zero_()
-        track = c.densify
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-        def run(bank):
-            ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
-                                 [bank[g]["v"] for g in GROUPS], (0.0,) * 6, 1, viewmat, K, self.W, self.H,
-                                 self.radii[:, :n], self.splats[:, :n], self.v_splats[:, :n], n=n, sh_degree=sd,
-                                 flags=self._flags() | ops.FLAG_PROBE, beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
-                                 stats={k: v[:n] for k, v in self.stats.items()} if track else None,
-                                 stat_use_abs=c.absgrad)
-
-        # in the real step the kernel finds nothing of its 3 GB in the 256 MB Infinity Cache (the rasteriser ran
-        # in between); evict it before every timed launch, or candidates are ranked on a warm cache
-        flush = torch.empty(384 << 20, dtype=torch.uint8, device=self.device)
-
-        def timed(bank) -> float:
-            best = float("inf")
-            run(bank)
-            for _ in range(3):
-                flush.zero_()
-                e0.record()
-                run(bank)
-                e1.record()
-                e1.synchronize()
-                best = min(best, e0.elapsed_time(e1))
-            return best
-
-        import random
-        import time
-        rng = random.Random(1234)
-        t_start = time.time()
-        report, graveyard = {}, []
-        # losers are held (so that the next candidate gets other pages) up to a memory budget: a quarter of
-        # what is free now, at most 16 GiB; beyond it the oldest are released
-        free_now = torch.cuda.mem_get_info(self.device)[0]
-        hold_budget = int(min(16 << 30, free_now // 4))
-
-        def bury(t):
-            graveyard.append(t)
-            held = sum(x.numel() * x.element_size() for x in graveyard)
-            while held > hold_budget and len(graveyard) > 1:
-                x = graveyard.pop(0)
-                held -= x.numel() * x.element_size()
-
-        # scatter some holes first: on a device whose free memory is one untouched expanse every candidate
-        # lands in much the same relative position (such boxes never got below 600 us)
-        blocks = [torch.empty(48 << 20, dtype=torch.uint8, device=self.device) for _ in range(min(48, hold_budget >> 27))]
-        graveyard.extend(blocks[0::2])
-        del blocks
-        shared = [(self.__dict__, k) for k in ("splats", "v_splats", "radii")] + [(self.stats, k) for k in self.stats]
-        spare = [bk for i, bk in enumerate(m.banks) if i != m.cur]
-        for bk in spare:                          # the spare bank has to hold real parameters while it is timed
-            for g in GROUPS:
-                bk[g]["p"].copy_(m.banks[m.cur][g]["p"])
-        best = [timed(bk) for bk in m.banks]
-        first = list(best)
-        n_vis = int((self.radii[:, :n] > 0).all(-1).sum())
-        target_ms = (n * 1424.0 + n_vis * 128.0) / 5.9e12 * 1e3
-        # Sweeps alternate between the banks: the candidates of the first sweep all come from the same
-        # untouched region of memory and often look alike; later ones land between the blocks the search
-        # itself has scattered, which is where the good layouts were found.
-        for sweep in range(sweeps):
-            improved = False
-            for b, bank in enumerate(m.banks):
-                slots = [(bank[g], k) for g in GROUPS for k in ("p", "m", "v")] + (shared if b == m.cur else [])
-                for holder, key in slots:
-                    old = holder[key]
-                    # a throw-away block of random size first, so that the candidate does not simply land
-                    # where the previous loser was (or right behind the last allocation)
-                    bury(torch.empty(rng.choice((1, 3, 7, 13, 29)) << 20, dtype=torch.uint8, device=self.device))
-                    if old.numel() * old.element_size() * 2 > hold_budget:
-                        continue                             # too large to keep a second copy around
-                    new = torch.empty_like(old)              # fresh pages: `old` is still held
-                    new.copy_(old)
-                    holder[key] = new
-                    t = timed(bank)
-                    if t < best[b] * (1.0 - min_gain):
-                        best[b] = t
-                        improved = True
-                        bury(old)
-                    else:
-                        holder[key] = old
-                        bury(new)
-                if b == m.cur:                     # the shared arrays moved: the other banks' times are stale
-                    for ob, obank in enumerate(m.banks):
-                        if ob != b:
-                            best[ob] = timed(obank)
-            # good enough = the kernel s algorithmic bytes at 5.9 TB/s (the best layouts seen reach 5.7)
-            # a layout that is still more than 8 % off the target gets a second helping of the budget
-            limit = budget_s * (2.0 if min(best) > 1.08 * target_ms else 1.0)
-            if max(best) <= target_ms or time.time() - t_start > limit:
-                break
-        for b in range(len(m.banks)):
-            report[f"bank{b}_first_us"], report[f"bank{b}_tuned_us"] = first[b] * 1e3, best[b] * 1e3
-        for bk in spare:
-            for g in GROUPS:
-                bk[g]["p"].zero_()
-        for v in self.stats.values():             # the timed launches counted visibility; nothing else changed
-            v.zero_()
-        del graveyard
-        torch.cuda.empty_cache()
-        if log is not None:
-            log("placement: fused backward " + ", ".join(
-                f"bank {b} {report[f'bank{b}_first_us']:.0f} -> {report[f'bank{b}_tuned_us']:.0f} us" for b in range(len(m.banks))))
-        return report
-
     def _grad_hooks(self):
         """Extra gradient terms between the backward and the optimiser (the MCMC regularisers)."""
         return
@@ -487,17 +363,25 @@ class Trainer:
 
     def _auto_cap_check(self, bad_bits: int = 0, scale: float = 1.0) -> None:
         """Where the host waits anyway (refine, periodic checks): grow the capacity when the running peak comes near it, or
-        when a view overflowed it (its lists were truncated for the steps since the last check, which is logged)."""
+        when a view overflowed it (its lists were truncated for the steps since the last check: reported through self.log,
+        counted in self.isect_overflows, which the CLI puts into the run's stats)."""
         if not (self.cfg.auto_isect_capacity and self.cfg.max_isect is None) or self._auto_cap is None:
             return
         peak = int(self._isect_peak.item())
         self._isect_peak.zero_()
         cap = self._auto_cap
         if (bad_bits & 4) or peak >= cap:
+            # the lists of some steps since the last check were cut at the capacity (their farthest splats missing): say so
             self.isect_overflows += 1
+            old = cap
             cap = 2 * max(cap, peak)
+            if self.log is not None:
+                self.log(f"tile-list capacity overflow absorbed: steps {self._last_cap_check_step}..{self.step_count} saw up to "
+                         f"{peak} intersections against a capacity of {old}; lists were truncated there, capacity now {cap} "
+                         f"(overflow #{self.isect_overflows})")
         elif peak > 0.6 * cap:
             cap = int(2.0 * peak) + (1 << 18)
+        self._last_cap_check_step = self.step_count
         self._auto_cap = max(cap, int(cap * scale))
 
     # -- DefaultStrategy.step_post_backward --------------------------------------------

@@ -1,5 +1,8 @@
 """Shared test inputs: small seeded scenes the CPU oracle finishes in seconds."""
+import json
 import math
+import os
+import time
 
 import torch
 
@@ -110,3 +113,58 @@ def isect_reference(radii, splats, tile_size, tw, th):
     keys, vals = keys[order], sel[rep][order]
     offs = torch.searchsorted((keys >> 32).contiguous(), torch.arange(C * tw * th, device=dev)).to(torch.int32)
     return tiles.to(torch.int32), keys, vals.to(torch.int32), offs.reshape(C, th, tw)
+
+
+# ------------------------------------------------- self-describing failures (VERDICT r2 #1b)
+EVIDENCE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_evidence")
+
+
+def _evidence(name, info):
+    """A failed bit-exact comparison says what differed: into the assertion message AND into a JSON file under
+    gpurun_out/test_evidence/ (merged back from the GPU box by gpurun)."""
+    try:
+        from mi3dgs import _lib
+        info["async_errors"] = _lib.async_errors(reset=False)
+    except Exception as e:                       # never let the reporting hide the failure
+        info["async_errors"] = f"unreadable: {e}"
+    info["name"] = name
+    try:
+        os.makedirs(EVIDENCE_DIR, exist_ok=True)
+        path = os.path.join(EVIDENCE_DIR, f"{name.replace('/', '_').replace(' ', '_')}_{int(time.time())}.json")
+        with open(path, "w") as f:
+            json.dump(info, f, indent=1)
+        info["evidence_file"] = path
+    except OSError:
+        pass
+    return json.dumps(info)
+
+
+def assert_clean(ops, what):
+    """The device error word right after a call, not at the end of the test: a chained kernel whose bounded wait ran out
+    (bits 1, 2) or a truncated list (bit 4) must not surface as a bare mismatch three assertions later."""
+    bad = ops._lib.async_errors(reset=False)
+    assert bad == 0, _evidence(what, dict(kind="device error word set", bits=bad))
+
+
+def assert_same(name, got, ref, **ctx):
+    """torch.equal that keeps its evidence: shapes, how many entries differ, the first differing index with the values
+    around it on both sides, the device error word, and whatever context the caller passes (counts, modes)."""
+    if got.shape == ref.shape and torch.equal(got, ref):
+        return
+    info = dict(kind="tensor mismatch", shape_got=list(got.shape), shape_ref=list(ref.shape),
+                ctx={k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in ctx.items()})
+    if got.shape == ref.shape:
+        g, r = got.flatten(), ref.flatten()
+        diff = g != r
+        idx = torch.nonzero(diff).flatten()
+        first, last = int(idx[0]), int(idx[-1])
+        lo, hi = max(0, first - 2), min(g.numel(), first + 6)
+        info.update(n_entries=g.numel(), n_differing=int(diff.sum()), first_index=first, last_index=last,
+                    got_around_first=g[lo:hi].tolist(), ref_around_first=r[lo:hi].tolist())
+    raise AssertionError(_evidence(name, info))
+
+
+def assert_count(name, got, expected, **ctx):
+    if int(got) != int(expected):
+        raise AssertionError(_evidence(name, dict(kind="count mismatch", got=int(got), expected=int(expected), delta=int(got) - int(expected),
+                                                  ctx={k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in ctx.items()})))

@@ -38,8 +38,42 @@ def test_library_exports_every_declared_symbol(built):
     h = ctypes.CDLL(built.LIB_PATH)
     for name in _declared():
         assert hasattr(h, name)
-    assert built.lib().mi3dgs_abi_version() == 3
+    assert built.lib().mi3dgs_abi_version() == 4
     assert built.lib().mi3dgs_splat_stride() == 16 and built.lib().mi3dgs_grad_stride() == 16
+
+
+TUNING_KNOBS = {"MI3DGS_OS_SMALL_KEYS", "MI3DGS_OS_MAX_KEYS", "MI3DGS_EMIT_SMALL_SPLATS", "MI3DGS_KEYS16"}      # include/mi3dgs.h
+
+
+def _env_names(path):
+    return set(re.findall(rb"MI3DGS_[A-Z0-9_]+", open(path, "rb").read()))
+
+
+def test_product_library_holds_no_experiment_switch(built):
+    """everything that can return wrong results and every rejected variant is compiled out of the product;
+    the only environment variables it reads are the documented thresholds."""
+    assert {n.decode() for n in _env_names(built.LIB_PATH)} == TUNING_KNOBS
+    header = open(HEADER).read()
+    for k in TUNING_KNOBS:
+        assert k in header, f"{k} is not documented in include/mi3dgs.h"
+    # the experiments build exists next to it, exports the same ABI, and is where those switches went
+    assert os.path.isfile(built.EXP_LIB_PATH)
+    exp = {n.decode() for n in _env_names(built.EXP_LIB_PATH)}
+    assert TUNING_KNOBS < exp and "MI3DGS_OS_NOLOOKBACK" in exp
+    out = subprocess.run(["nm", "-D", "--defined-only", built.EXP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert sorted(set(re.findall(r" T (mi3dgs_[a-z0-9_]+)", out))) == _declared()
+    assert os.path.getsize(built.LIB_PATH) < os.path.getsize(built.EXP_LIB_PATH)
+    # and the product refuses the rasteriser modes that only the experiments build has
+    assert built.lib().mi3dgs_debug_set_raster_mode(1) == 0
+    for mode in (0, 3, 11, 14):
+        assert built.lib().mi3dgs_debug_set_raster_mode(mode) != 0
+    # nothing under the package reads an experiment switch from the environment any more
+    pkg = os.path.join(ROOT, "pipeline-pointcloud_amd", "mi3dgs")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            txt = open(os.path.join(pkg, f)).read()
+            for k in ("MI3DGS_BWD_EXPERIMENT", "MI3DGS_RASTER_MODE", "MI3DGS_EMIT_MODE", "MI3DGS_SORT_MODE", "MI3DGS_TUNE_PLACEMENT"):
+                assert k not in txt, (f, k)
 
 
 def test_workspace_queries_are_host_only(built):

@@ -125,12 +125,14 @@ def test_single_process_context_is_inactive():
 
 
 # ------------------------------------------------------------- sharded optimiser
-def _torch_adam_step(params, grads, exp_avg, exp_avg_sq, lrs, step, beta1=0.9, beta2=0.999, eps=1e-15, numel=None):
+def _torch_adam_step(params, grads, exp_avg, exp_avg_sq, lrs, step, beta1=0.9, beta2=0.999, eps=1e-15, numel=None, grad_scale=1.0):
     """Stand-in for ops.adam_step on CPU tensors (torch.optim.Adam arithmetic); the HIP kernel itself is checked
     against torch.optim.Adam on the GPU (tests/test_gpu_configs.py)."""
     for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avg, exp_avg_sq)):
         n = p.numel() if numel is None else int(numel[i])
         pf, gf, mf, vf = p.reshape(-1)[:n], g.reshape(-1)[:n], m.reshape(-1)[:n], v.reshape(-1)[:n]
+        if grad_scale != 1.0:
+            gf = gf * grad_scale              # what the HIP kernel does on the way in (mi3dgs_adam_step, grad_scale)
         mf.mul_(beta1).add_(gf, alpha=1 - beta1)
         vf.mul_(beta2).addcmul_(gf, gf, value=1 - beta2)
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step

@@ -14,7 +14,7 @@ import math
 import pytest
 import torch
 
-from helpers import activated, crop_camera, isect_reference, rel_err, wolf_scene
+from helpers import activated, assert_clean, assert_count, assert_same, crop_camera, isect_reference, rel_err, wolf_scene
 from oracle import gs_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -117,29 +117,48 @@ def test_full_size_binning_bit_exact_and_raster_properties(dev, kind, cam):
     tpg_r, ids_r, flat_r, offs_r = isect_reference(radii, splats, 16, tw, th)
     I = ids_r.numel()
     assert I > 10 * tw * th
+    # (every comparison keeps its evidence on a mismatch -- count deltas, first differing index, the device error word -- and
+    #  the error word is read after EVERY binning call: helpers.assert_same / assert_count / assert_clean)
+    tag = f"full_size_binning/{kind}"
     b = ops.bin_tiles(radii, splats, W, H, 16, want_isect_ids=True, want_tiles_per_gauss=True, tight=False)
-    assert int(b["n_isect"].item()) == I == int(b["tiles_per_gauss"].sum())
-    assert torch.equal(b["tiles_per_gauss"], tpg_r)
-    assert torch.equal(b["isect_ids"], ids_r)
-    assert torch.equal(b["flatten_ids"], flat_r)
-    assert torch.equal(b["isect_offsets"], offs_r)
+    assert_clean(ops, f"{tag}/two-phase box")
+    assert_count(f"{tag}/two-phase box n_isect", b["n_isect"].item(), I, tiles_per_gauss_sum=int(b["tiles_per_gauss"].sum()))
+    assert I == int(b["tiles_per_gauss"].sum())
+    assert_same(f"{tag}/two-phase box tiles_per_gauss", b["tiles_per_gauss"], tpg_r)
+    assert_same(f"{tag}/two-phase box isect_ids", b["isect_ids"], ids_r)
+    assert_same(f"{tag}/two-phase box flatten_ids", b["flatten_ids"], flat_r)
+    assert_same(f"{tag}/two-phase box isect_offsets", b["isect_offsets"], offs_r)
     # (2) the same lists from the fused capacity path (what the training step runs), keys from the projection
     bf = ops.bin_tiles(radii, splats, W, H, 16, max_isect=I + 4096, tight=False, fused=True, depth_keys=keys.clone(),
                        want_tiles_per_gauss=True)
-    assert int(bf["n_isect"].item()) == I
-    assert torch.equal(bf["flatten_ids"][:I], flat_r) and torch.equal(bf["isect_offsets"], offs_r)
-    assert torch.equal(bf["tiles_per_gauss"], tpg_r)
+    assert_clean(ops, f"{tag}/fused box")
+    assert_count(f"{tag}/fused box n_isect", bf["n_isect"].item(), I, tiles_per_gauss_sum=int(bf["tiles_per_gauss"].sum()))
+    assert_same(f"{tag}/fused box flatten_ids", bf["flatten_ids"][:I], flat_r)
+    assert_same(f"{tag}/fused box isect_offsets", bf["isect_offsets"], offs_r)
+    assert_same(f"{tag}/fused box tiles_per_gauss", bf["tiles_per_gauss"], tpg_r)
     # (3) exact ellipse culling: a subset of the box lists, same order inside every tile, identical render
     bt = ops.bin_tiles(radii, splats, W, H, 16, max_isect=I + 4096, tight=True, fused=True, depth_keys=keys.clone(),
                        want_tiles_per_gauss=True, radii_in_records=True)      # exactly the training step's call
+    assert_clean(ops, f"{tag}/fused tight")
     It = int(bt["n_isect"].item())
-    assert 0 < It <= I and It == int(bt["tiles_per_gauss"].sum())
+    assert 0 < It <= I
+    assert_count(f"{tag}/fused tight n_isect vs its own tiles_per_gauss", It, int(bt["tiles_per_gauss"].sum()), box_count=I)
+    # the two-phase path (exact allocation, separate count and emit kernels, no dropped sentinels in the depth sort) gives the
+    # same tight lists: an independent second route to every number below
+    bt2 = ops.bin_tiles(radii, splats, W, H, 16, tight=True, fused=False, radii_in_records=True)
+    assert_clean(ops, f"{tag}/two-phase tight")
+    assert_count(f"{tag}/fused tight n_isect vs two-phase tight", It, bt2["n_isect"].item(), box_count=I)
+    assert_same(f"{tag}/fused tight flatten_ids vs two-phase", bt["flatten_ids"][:It], bt2["flatten_ids"][:It], n_isect=It)
+    assert_same(f"{tag}/fused tight isect_offsets vs two-phase", bt["isect_offsets"], bt2["isect_offsets"], n_isect=It)
     # the training step's and the renderer's call does not ask for the sorted tile keys back: the library then sorts 16-bit
     # keys (garden and 6m are above the switch-over to the classic passes, lego below it) -- the same lists bit for bit
     b16 = ops.bin_tiles(radii, splats, W, H, 16, max_isect=I + 4096, tight=True, fused=True, depth_keys=keys.clone(),
                         radii_in_records=True, want_tile_keys=False)
-    assert b16["tile_keys"] is None and int(b16["n_isect"].item()) == It
-    assert torch.equal(b16["flatten_ids"][:It], bt["flatten_ids"][:It]) and torch.equal(b16["isect_offsets"], bt["isect_offsets"])
+    assert_clean(ops, f"{tag}/fused tight 16-bit keys")
+    assert b16["tile_keys"] is None
+    assert_count(f"{tag}/fused tight 16-bit keys n_isect", b16["n_isect"].item(), It, box_count=I)
+    assert_same(f"{tag}/fused tight 16-bit keys flatten_ids", b16["flatten_ids"][:It], bt["flatten_ids"][:It], n_isect=It)
+    assert_same(f"{tag}/fused tight 16-bit keys isect_offsets", b16["isect_offsets"], bt["isect_offsets"], n_isect=It)
     tk, fi = bt["tile_keys"][:It].long(), bt["flatten_ids"][:It].long()
     assert bool((tk[1:] >= tk[:-1]).all())
     d = splats.view(-1, ops.SPLAT_STRIDE)[fi, 9]
@@ -260,7 +279,7 @@ def test_adam_two_million_matches_torch_optim(dev):
 def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad, with_bg):
     """The product backward contracts its per-splat pixel sums on the matrix pipe, carrying every term as two bf16 values
     (csrc/rasterize_bwd_mm.hip); the reduce-scatter kernel of the first half of round 2 sums the same terms in float32 on
-    the vector pipe (MI3DGS_RASTER_MODE=3).  Same forward, same lists: the gradient records must agree to the transport's
+    the vector pipe (experiments library, mode 3).  Same forward, same lists: the gradient records must agree to the transport's
     2^-16 per term -- checked on the full S1 / S2 scenes, with and without background and |d/dxy| sums."""
     ops = _ops()
     sc = _scene(kind)
@@ -272,14 +291,21 @@ def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad
     gen = torch.Generator().manual_seed(9)
     vr = (torch.rand(1, H, W, 3, generator=gen) - 0.5).to(dev)
     va = (torch.rand(1, H, W, 1, generator=gen) - 0.5).to(dev)
-    lib = ops._lib.lib()
-    outs = []
+    # the product backward from the product library; the all-f32 reduce-scatter backward only exists in the experiments
+    # build (libmi3dgs_exp.so, mode 3), called here through its own handle on the same device buffers
+    import ctypes as C
+    mm_out = ops.rasterize_bwd(splats, b, W, H, a, l, vr, va, 16, bg, absgrad).clone()
+    ex = ops._lib.experiments_lib()
+    assert ex.mi3dgs_debug_set_raster_mode(3) == 0
+    rs_out = torch.zeros_like(mm_out)
     try:
-        for mode in (1, 3):
-            lib.mi3dgs_debug_set_raster_mode(mode)
-            outs.append(ops.rasterize_bwd(splats, b, W, H, a, l, vr, va, 16, bg, absgrad).clone())
+        ops._lib.exp_call("mi3dgs_rasterize_bwd", 1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
+                          ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(a), ops._p(l), ops._p(vr), ops._p(va),
+                          int(absgrad), ops._p(rs_out), ops._stream(dev))
+        torch.cuda.synchronize()
     finally:
-        lib.mi3dgs_debug_set_raster_mode(1)
+        ex.mi3dgs_debug_set_raster_mode(1)
+    outs = [mm_out, rs_out]
     mm, rs = outs
     assert bool(torch.isfinite(mm).all()) and float(rs.abs().sum()) > 0
     ncol = 11 if absgrad else 9

@@ -683,35 +683,6 @@ def test_mcmc_regulariser_gradients_match_autograd(dev):
     assert rel_err(vo.cpu(), 2 * o.grad) < 1e-5 and rel_err(vs.cpu(), 2 * sl.grad) < 1e-5
 
 
-def test_placement_tuning_is_a_no_op_on_the_model(dev, monkeypatch):
-    monkeypatch.setenv("MI3DGS_SEPARATE_ARRAYS", "1")      # the search works on separately allocated arrays (round-1 layout)
-    """tune_placement() re-allocates arrays and times the fused kernel as an exact no-op: parameters, moments and
-    densify statistics are what they were, and training afterwards is what it would have been."""
-    from mi3dgs import trainer
-    sc = small_scene(n=3000, seed=41, width=96, height=64, n_views=2).to(dev)
-    imgs = torch.rand(2, 64, 96, 3, generator=torch.Generator().manual_seed(0)).to(dev)
-    runs = []
-    for tune in (False, True):
-        tr = trainer.Trainer({k: v.clone() for k, v in sc.params.items()}, sc.viewmats, sc.Ks, imgs, 96, 64,
-                             trainer.TrainConfig(capacity=4000, refine_start_iter=10 ** 9))
-        before = {g: tr.model.p(g).clone() for g in trainer.GROUPS}
-        if tune:
-            rep = tr.tune_placement(sweeps=1, min_gaussians=0)
-            assert rep["bank0_tuned_us"] <= rep["bank0_first_us"] and "bank1_tuned_us" in rep
-            for g in trainer.GROUPS:
-                assert torch.equal(tr.model.p(g), before[g])
-                for b in range(2):
-                    assert float(tr.model.banks[b][g]["m"].abs().max()) == 0 and float(tr.model.banks[b][g]["v"].abs().max()) == 0
-                assert float(tr.model.banks[1 - tr.model.cur][g]["p"].abs().max()) == 0
-            assert all(float(v.abs().max()) == 0 for v in tr.stats.values())
-            assert tr.tune_placement() == {}                              # too few Gaussians for the default threshold
-        losses = [tr.step(i % 2, want_loss=True) for i in range(5)]
-        assert tr.tune_placement() == {}
-        runs.append((losses, tr.model.p("means").clone(), tr.stats["count"].clone()))
-    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and torch.allclose(runs[0][1], runs[1][1], atol=1e-6)
-    assert torch.equal(runs[0][2], runs[1][2])
-
-
 def test_no_chained_kernel_gave_up_waiting(dev):
     """The device-wide scan, the onesweep radix passes and the fused tile emit wait on one another with
     bounded spins; a wait that runs out leaves a bit in a sticky device word (and Trainer.refine raises on

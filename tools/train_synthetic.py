@@ -29,7 +29,11 @@ def main():
     ap.add_argument("--mode", default="simple_trainer", choices=["simple_trainer", "ns-train"])
     ap.add_argument("--strategy", default="default", choices=["default", "mcmc"])
     ap.add_argument("--keep", default=None, help="directory to keep the dataset and outputs in")
-    a = ap.parse_args()
+    ap.add_argument("--seed-noise", type=float, default=0.01, help="jitter of the SfM-like seed points")
+    ap.add_argument("--backdrop", type=int, default=20_000,
+                    help="Gaussians of an opaque shell (radius 25) around the scene, so that every pixel shows content like a "
+                         "photograph (0 = none: uncovered pixels then carry the constant background 0.2, the round-1/2 dataset)")
+    a, extra = ap.parse_known_args()         # extra: passed on to the shim (e.g. --opacity_reg 0.005)
     from PIL import Image
     from mi3dgs import cli, io_colmap, scenes, trainer
     dev = torch.device("cuda:0")
@@ -40,6 +44,9 @@ def main():
                                  fx=1450.0 * a.width / 1920.0)
     sc.params["opacities"] += 1.5                          # a mostly opaque scene, like a trained one
     sc.params["scales"] += np.log(2.5 * (2_000_000 / a.gt) ** (1 / 3))   # keep the surface covered at lower counts
+    n_obj = a.gt
+    if a.backdrop > 0:
+        sc = scenes.add_backdrop(sc, a.backdrop, 25.0, (0.0, 0.0, 0.0))
     g = sc.to(dev)
     tr = trainer.Trainer(g.params, g.viewmats, g.Ks, torch.zeros(1, 1, 1, 3, device=dev), a.width, a.height,
                          trainer.TrainConfig(densify=False))
@@ -52,8 +59,14 @@ def main():
         Image.fromarray((img * 255).round().byte().cpu().numpy()).save(os.path.join(root, "images", f"f_{i:04d}.png"))
         V = sc.viewmats[i].double().numpy()
         ims.append(io_colmap.Image(i + 1, io_colmap.rotmat_to_qvec(V[:3, :3]), V[:3, 3].copy(), 1, f"f_{i:04d}.png"))
-    sel = torch.randperm(a.gt, generator=torch.Generator().manual_seed(1))[: a.points]
-    xyz = (sc.params["means"][sel] + 0.01 * torch.randn(a.points, 3)).double().numpy()
+    n_all = sc.params["means"].shape[0]
+    # SfM-like seeds: a.points of the scene's own Gaussians, plus the same fraction of the backdrop's
+    sel = torch.randperm(n_obj, generator=torch.Generator().manual_seed(1))[: a.points]
+    if n_all > n_obj:
+        k = max(1, int(round(a.backdrop * a.points / n_obj)))
+        sel = torch.cat([sel, n_obj + torch.randperm(n_all - n_obj, generator=torch.Generator().manual_seed(2))[:k]])
+    a.points = sel.numel()
+    xyz = (sc.params["means"][sel] + a.seed_noise * torch.randn(a.points, 3)).double().numpy()
     rgb = ((0.5 + 0.2820948 * sc.params["sh0"][sel, 0]).clamp(0, 1) * 255).byte().numpy()
     sparse = os.path.join(root, "sparse", "0") if a.mode == "simple_trainer" else os.path.join(root, "colmap", "sparse", "0")
     io_colmap.write_model(sparse, cams, ims, xyz, rgb)
@@ -65,13 +78,13 @@ def main():
         res = os.path.join(root, "exports")
         cli.main_simple_trainer([a.strategy, "--max_steps", str(a.steps), "--result-dir", res, "--data_factor", "1",
                                  "--steps_scaler", "1.0", "--disable_viewer", "--packed", "--batch-size", "1",
-                                 "--data-dir", root])
+                                 "--data-dir", root] + extra)
         st = json.load(open(os.path.join(res, "stats", f"val_step{a.steps - 1:04d}.json")))
     else:
         os.chdir(root)
         model = "splatfacto-mcmc" if a.strategy == "mcmc" else "splatfacto"
         cli.main_ns_train([model, "--timestamp", "train-stage-1", "--pipeline.model.use_scale_regularization=True",
-                           "--max-num-iterations", str(a.steps), "colmap", "--data", root, "--downscale-factor", "1"])
+                           "--max-num-iterations", str(a.steps)] + extra + ["colmap", "--data", root, "--downscale-factor", "1"])
         st = json.loads("".join(l for l in open("outputs/unnamed/splatfacto/train-stage-1/config.yml") if not l.startswith("#")))["stats"]
     print("[synthetic] result:", json.dumps(st), flush=True)
 

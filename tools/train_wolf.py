@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--points", type=int, default=9000)
     ap.add_argument("--steps", type=int, default=7000)
     ap.add_argument("--model", default="splatfacto")
-    a = ap.parse_args()
+    ap.add_argument("--backdrop", type=int, default=12_000,
+                    help="Gaussians of an opaque, smoothly coloured shell around the wolf (radius 9 x its extent): every pixel shows "
+                         "content, like a photograph in a room (0 = none: constant background 0.15, the round-2 dataset)")
+    a, extra = ap.parse_known_args()         # extra: passed on to ns-train
     from PIL import Image
     from helpers import load_wolf
     from mi3dgs import cli, io_colmap, io_ply, scenes, trainer
@@ -42,6 +45,10 @@ def main():
     n = P["means"].shape[0]
     centre = P["means"].median(0).values
     ext = float((P["means"] - centre).abs().quantile(0.99))
+    n_obj = n
+    if a.backdrop > 0:
+        P = scenes.add_backdrop(scenes.Scene("wolf", P, None, None, a.width, a.height), a.backdrop, 9.0 * ext, tuple(centre.tolist())).params
+        n = P["means"].shape[0]
     g = {k: v.to(dev) for k, v in P.items()}
     fx = 1.25 * a.width
     vms, ks = [], []
@@ -64,7 +71,11 @@ def main():
         Image.fromarray((img[0].clamp(0, 1) * 255).round().byte().cpu().numpy()).save(os.path.join(root, "images", f"f_{i:04d}.png"))
         V = vms[i].double().numpy()
         ims.append(io_colmap.Image(i + 1, io_colmap.rotmat_to_qvec(V[:3, :3]), V[:3, 3].copy(), 1, f"f_{i:04d}.png"))
-    sel = torch.randperm(n, generator=torch.Generator().manual_seed(1))[: a.points]
+    sel = torch.randperm(n_obj, generator=torch.Generator().manual_seed(1))[: a.points]
+    if n > n_obj:           # the same fraction of the backdrop's Gaussians as seeds
+        k = max(1, int(round(a.backdrop * a.points / n_obj)))
+        sel = torch.cat([sel, n_obj + torch.randperm(n - n_obj, generator=torch.Generator().manual_seed(2))[:k]])
+    a.points = sel.numel()
     xyz = (P["means"][sel] + 0.002 * ext * torch.randn(a.points, 3)).double().numpy()
     rgb = ((0.5 + 0.2820948 * P["sh0"][sel, 0]).clamp(0, 1) * 255).byte().numpy()
     io_colmap.write_model(os.path.join(root, "colmap", "sparse", "0"), cams, ims, xyz, rgb)
@@ -77,8 +88,8 @@ def main():
     t0 = time.time()
     cli.main_ns_train([a.model, "--timestamp", "train-stage-1", "--viewer.quit-on-train-completion=True",
                        "--logging.local-writer.enable", "False", "--logging.profiler", "none",
-                       "--pipeline.model.use_scale_regularization=True", "--max-num-iterations", str(a.steps),
-                       "colmap", "--data", root, "--downscale-factor", "1"])
+                       "--pipeline.model.use_scale_regularization=True", "--max-num-iterations", str(a.steps)] + extra +
+                      ["colmap", "--data", root, "--downscale-factor", "1"])
     base = os.path.join("outputs", "unnamed", "splatfacto", "train-stage-1")
     cli.main_ns_export(["gaussian-splat", "--load-config", os.path.join(base, "config.yml"), "--output-dir", os.path.join(root, "exports")])
     st = json.loads("".join(l for l in open(os.path.join(base, "config.yml")) if not l.startswith("#")))["stats"]
