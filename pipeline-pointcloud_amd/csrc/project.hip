@@ -12,6 +12,7 @@
 // 236 + 64 B read, 236 B written.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -563,6 +564,9 @@ __device__ __forceinline__ void slice_store(float* dst, const float* lds, int co
 // writing and re-reading the gradients disappear, and the shN group (76 % of all parameters)
 // is updated with whole-wave 16-byte accesses.  Parameters are then read and written through
 // the same pointers, hence no __restrict__ on them.
+// (Round 3, measured and removed: starting the three blocks a CU holds first 6 - 35 us apart, against the idea that the whole
+// GPU computes and then streams in lockstep: 541.8 - 555.5 us against 544.4 us without, profiles/r03_bwd_adam_stagger_ab.txt.
+// The phases' times add up because each wave's life is a serial chain, not because the waves march in step.)
 struct FusedAdam {
     float* m[6];            // means, quats, scales, opacities, sh0, shN
     float* v[6];

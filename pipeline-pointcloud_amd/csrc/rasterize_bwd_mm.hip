@@ -32,6 +32,11 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int TR_STRIDE = 68;
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
+// Splats per staged batch = one per thread.  Round 3 measured 128 (LDS 39.7 KB, room for four blocks per CU) with the kernel
+// held to 128 VGPRs for four waves per SIMD: 39 registers spilled to scratch, 515 us against 477 us on S2 and 169 against 147 us
+// on S1; the same 128-slot batches at three waves per SIMD 486 / 152 us (profiles/r03_raster_bwd_occupancy_ab.txt).  The fourth
+// wave has to come from ~40 fewer registers, not from the compiler's spiller.
+constexpr int STG = BLOCK;
 // columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums, then |x|, |y|
 constexpr int AW_ABSX = 12, AW_ABSY = 13;       // 9..11: the lo colour sums
 
@@ -41,10 +46,10 @@ constexpr int AW_ABSX = 12, AW_ABSY = 13;       // 9..11: the lo colour sums
 template <bool ABSGRAD>
 struct StagedBwdMM {
     static constexpr int AW = ABSGRAD ? 14 : 12;
-    Staged f;
-    float4 geo[BLOCK];        // mx, my (relative to the tile centre), A, B
-    float2 geo2[BLOCK];       // C, 1 / o
-    int id[BLOCK];
+    StagedN<STG> f;
+    float4 geo[STG];          // mx, my (relative to the tile centre), A, B
+    float2 geo2[STG];         // C, 1 / o
+    int id[STG];
     float accw[4][GRP][AW];
     unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (value, splat of the chunk), columns = the wave's 64 pixels
     unsigned long long gmask[4];        // per wave: slots of the current group whose visit was live (its sums are meaningful)
@@ -68,6 +73,21 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& wa, unsigned&
     wb = hb | (l >> 16);
 }
 
+// three terms (experiments build, A/B of VERDICT r2 #3): hi and mid are exact truncations, lo is rounded -- 24 significant bits.
+// Word A = hi | mid, word B = lo | 0; both multiply the same basis, so the two words are two more ROWS of the same product
+// whose results add up.
+__device__ __forceinline__ void split3w(float a, unsigned& wA, unsigned& wB) {
+#pragma clang fp contract(off)
+    const unsigned h = f32_hi(a);
+    const float r1 = a - __builtin_bit_cast(float, h);
+    const unsigned m = f32_hi(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    const f2v r = {r2, 0.f};
+    const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v)) & 0xFFFFu;
+    wA = h | (m >> 16);
+    wB = l;
+}
+
 // The contraction of a chunk is software-pipelined against the visits of the NEXT chunk: its A operands are read when its last
 // visit has stored (LDS executes a wave's instructions in order, so the next chunk's stores to the same rows stay behind these
 // reads), its 4 MFMAs are issued one per visit between the vector instructions of the following visits, and its
@@ -88,11 +108,15 @@ __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
 // WF (variant, MI3DGS_RASTER_MODE=14): the wave turns its own chunk's sums into gradient records and adds them to global
 // memory itself -- no per-wave sums kept for a block flush, no group barriers, but one 64-byte float-atomic request per
 // (quadrant, splat) instead of one per (tile, splat).
-template <bool ABSGRAD, bool WF>
+template <bool ABSGRAD, bool WF, bool T3 = false>
 __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
                                           float* __restrict__ v_splats) {
     constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
-    constexpr int CH = ABSGRAD ? 4 : 8;
+    constexpr int CH = (ABSGRAD || T3) ? 4 : 8;
+    if (T3) {          // rows 8..15 (lanes 32..63) hold the sums of the third term: add them to rows 0..7
+#pragma unroll
+        for (int r = 0; r < 4; r++) P.d[r] += __shfl_down(P.d[r], 32, 64);
+    }
     if (mm.acc_off >= 0) {
         float* a = &L.accw[wv][WF ? 0 : P.slot0][0] + mm.acc_off;
         a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3];
@@ -142,13 +166,13 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int 
     P.on = true;
 }
 
-template <bool ABSGRAD, bool WF>
+template <bool ABSGRAD, bool WF, bool T3 = false>
 __device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
                                          float* __restrict__ v_splats) {
     if (!P.on) return;
 #pragma unroll
     for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
-    mm_finish<ABSGRAD, WF>(L, P, mm, wv, lane, v_splats);
+    mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
 }
 
 // One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
@@ -160,7 +184,8 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
                                                  MMPend& P, unsigned long long& gmask, const float (&vrgb)[3], float tail,
                                                  float& T, float& bufdot, float* __restrict__ v_splats) {
     constexpr bool WF = (EXP & 4) != 0;
-    constexpr int CH = ABSGRAD ? 4 : 8;          // splats per chunk: CH x (2 or 4 values) = 16 rows
+    constexpr bool T3 = (EXP & 8) != 0 && !ABSGRAD;      // three-term transport (experiments build)
+    constexpr int CH = (ABSGRAD || T3) ? 4 : 8;  // splats per chunk: CH x (2 or 4 values) = 16 rows
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
     // colours two visits ahead: LDS serves a wave in order, so a read queues behind the two stores of the visit before it
@@ -197,7 +222,15 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
             const unsigned long long gon = valid & mask_le(s[i], LOG2_MAX_ALPHA);
             const float q = lane_of(gon) ? alpha * v_alpha : 0.f;
             unsigned wq, wf;
-            split2(q, fac, wq, wf);
+            if (T3) {
+                unsigned wq2, wf2;
+                split3w(q, wq, wq2);
+                split3w(fac, wf, wf2);
+                trw[(2 * CH + ci) * TR_STRIDE] = wq2;
+                trw[(3 * CH + ci) * TR_STRIDE] = wf2;
+            } else {
+                split2(q, fac, wq, wf);
+            }
             trw[ci * TR_STRIDE] = wq;
             trw[(CH + ci) * TR_STRIDE] = wf;
             if (ABSGRAD) {
@@ -211,7 +244,7 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
             }
         }
         if (ci == CH - 1) {
-            if (P.on) mm_finish<ABSGRAD, WF>(L, P, mm, wv, lane, v_splats);
+            if (P.on) mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
             const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
             if (cl) {
                 mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
@@ -334,6 +367,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
         if (ABSGRAD) {
             // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3
             mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : (j == 5 ? (g == 2 ? AW_ABSX : AW_ABSY) : -1);
+        } else if ((EXP & 8) != 0) {
+            // three terms: rows Q 0..3, W 4..7 (words hi | mid), Q 8..11, W 12..15 (words lo | 0); groups 2, 3 are added to 0, 1 in mm_finish
+            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : -1;
         } else {
             // rows: Q 0..7, W 8..15  ->  groups 0, 1 hold Q of splats 4 g + r, groups 2, 3 hold W of splats 4 (g - 2) + r
             const int col = g < 2 ? (j < 6 ? j : -1) : (j >= 6 && j < 12 ? j : -1);
@@ -346,9 +382,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
     const unsigned long long has = wave_ballot(bin_final >= 0);
     MMPend P;
     P.on = false;
-    for (int be = bmax; be >= start; be -= BLOCK) {
+    for (int be = bmax; be >= start; be -= STG) {
         __syncthreads();
-        {
+        if (threadIdx.x < STG) {
             const int j1 = be - (int)threadIdx.x;
             const int id_cur = j1 >= start ? flatten_ids[j1] : -1;
             const RecRegs rec = load_rec(splats, id_cur);
@@ -360,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
             }
         }
         __syncthreads();
-        const int bsz = min(BLOCK, be - start + 1);
+        const int bsz = min(STG, be - start + 1);
         const int k0 = max(0, be - wmax);            // wave-uniform: nothing in this wave is live before slot k0
         for (int g0 = 0; g0 < bsz; g0 += GRP) {      // block-uniform: groups of 64 slots
             unsigned long long gmask = 0ull;
@@ -374,7 +410,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
                 else
                     bwd_sub_batch_mm<ABSGRAD, false, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
             }
-            mm_drain<ABSGRAD, (EXP & 4) != 0>(L, P, mm, wv, lane, v_splats);
+            mm_drain<ABSGRAD, (EXP & 4) != 0, (EXP & 8) != 0 && !ABSGRAD>(L, P, mm, wv, lane, v_splats);
             if (EXP & 5) continue;          // 1: timing experiment, no group barriers, no flush; 4: the waves have flushed themselves
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
@@ -448,6 +484,11 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
 #ifdef MI3DGS_EXPERIMENTS
+    if (experiment == 4 && !absgrad) {           // three-term transport of the pixel sums (correct results, 24 significant bits)
+        if (backgrounds) LAUNCH_MM(true, false, 8); else LAUNCH_MM(false, false, 8);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
     if (experiment == 14) {           // wave-flush variant (correct results)
         if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4); else LAUNCH_MM(true, false, 4); }
         else { if (absgrad) LAUNCH_MM(false, true, 4); else LAUNCH_MM(false, false, 4); }

@@ -50,11 +50,15 @@ __device__ __forceinline__ void quad_coefs(float x, float y, float A, float B, f
 // the first instruction and 16, 17 of the second, lanes 32..63 slots 8..15.
 typedef unsigned qu4 __attribute__((ext_vector_type(4)));
 typedef __bf16 qbf8 __attribute__((ext_vector_type(8)));
-struct Staged {
-    qu4 coefA[BLOCK / SUB][2][SUB];      // A operand of the first instruction: [sub-batch][lane half][row] = 8 bf16
-    unsigned coefB[BLOCK / SUB][SUB];    // A operand of the second: slots 16, 17 (lanes 0..31; the other 14 slots are zero)
-    float4 uni[BLOCK + 2];               // per splat, wave-uniform in the chain: r, g, b (read one or two visits ahead)
+// SLOTS = splats per staged batch: 256 in the forward (one record per thread), 128 in the backward (its LDS has to leave
+// room for four blocks per CU: rasterize_bwd_mm.hip)
+template <int SLOTS>
+struct StagedN {
+    qu4 coefA[SLOTS / SUB][2][SUB];      // A operand of the first instruction: [sub-batch][lane half][row] = 8 bf16
+    unsigned coefB[SLOTS / SUB][SUB];    // A operand of the second: slots 16, 17 (lanes 0..31; the other 14 slots are zero)
+    float4 uni[SLOTS + 2];               // per splat, wave-uniform in the chain: r, g, b (read one or two visits ahead)
 };
+typedef StagedN<BLOCK> Staged;
 
 // A splat record as the rasterisers use it: fetched one batch AHEAD of its use (the loads of batch b + 1 are issued
 // before batch b is composited; a tile's list is walked in batches of 256 and the gather used to sit, fully exposed,
@@ -85,7 +89,8 @@ __device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned sho
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
-__device__ __forceinline__ void stage_splat(Staged& L, int slot, const RecRegs& r, float xc, float yc) {
+template <typename STAGED>
+__device__ __forceinline__ void stage_splat(STAGED& L, int slot, const RecRegs& r, float xc, float yc) {
     float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -INFINITY};      // padding: alpha = 2^-inf = 0
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r.bb.y > 0.f) {
@@ -149,7 +154,8 @@ __device__ __forceinline__ Basis make_basis(int wave, int lane) {
 
 // log2 alpha (opacity folded in, NOT yet clamped) of this lane's pixel against the 32 splats of sub-batch
 // `sb`: s[i] for row i in depth order.
-__device__ __forceinline__ void eval_sub_batch(const Staged& L, int sb, int lane, const Basis& b, float s[SUB]) {
+template <typename STAGED>
+__device__ __forceinline__ void eval_sub_batch(const STAGED& L, int sb, int lane, const Basis& b, float s[SUB]) {
     const int h = lane >> 5, row = lane & 31;
     const qu4 a1 = L.coefA[sb][h][row];
     const unsigned a2w = L.coefB[sb][row];

@@ -146,7 +146,7 @@ class DataParallelMixin:
         per step   reduce_scatter(gradients, sum)  ->  Adam on this rank's 1/G slice  ->  all_gather(parameters)
         at refine  all_gather(exp_avg), all_gather(exp_avg_sq) (each rank only keeps its slice current), all-reduce
                    of the densify statistics (sum, sum, max); then the identical surgery everywhere.
-      xGMI bytes per rank and step: 2 x (G-1)/G x 236 B x capacity  (6 M Gaussians, G = 8: 2.5 GB), against
+      xGMI bytes per rank and step: 2 x (G-1)/G x 236 B x live rows  (6 M Gaussians, G = 8: 2.5 GB), against
       2 x that for the dense all-reduce, and 1/G of the Adam traffic (1 652 B per Gaussian) instead of all of it.
     shard_optimizer=False (round 1): one dense all-reduce per group, the full Adam step on every rank."""
 
@@ -158,7 +158,7 @@ class DataParallelMixin:
     def _model_layout(self) -> Dict:
         ctx = getattr(self, "_pending_ctx", None)
         world = ctx.world if ctx is not None else 1
-        if getattr(self, "_pending_shard", False) and world > 1:
+        if getattr(self, "_pending_shard", False) and ctx is not None and ctx.active:
             return dict(flat=True, align=4 * world)            # slices stay 16-byte aligned
         return {}
 
@@ -170,20 +170,33 @@ class DataParallelMixin:
         return not self.ctx.active          # the gradients have to exist to be reduced
 
     # -- the optimiser step --------------------------------------------------------------
-    def _slice_pieces(self):
-        """This rank's slice of the flat buffers as (group index, first element, count) pieces."""
-        m = self.model
-        tot = sum(WIDTHS) * m.capacity
-        L = tot // self.ctx.world
-        lo, hi = self.ctx.rank * L, (self.ctx.rank + 1) * L
+    # The exchange is per parameter group over the LIVE rows: rank r owns rows [r R / G, (r + 1) R / G) of every
+    # group, R = the live count rounded up to 4 G rows (so that every slice of every width starts 16-byte aligned; the model's
+    # capacity is a multiple of 4 G).  Round 2 cut the flat buffers by CAPACITY: with n < capacity (the normal case: capacity =
+    # max_gaussians) the high ranks owned nothing but padding, a few ranks did all of the Adam work (shN is 45/59 of the
+    # buffer), and the padding travelled over xGMI every step.
+    def _exchange_rows(self) -> int:
+        m, q = self.model, 4 * self.ctx.world
+        return min(m.capacity, (m.n + q - 1) // q * q)
+
+    def _group_spans(self):
+        """(group index, first float of the group in the flat buffers, floats of its exchanged rows)."""
+        m, R = self.model, self._exchange_rows()
         out, off = [], 0
         for gi, w in enumerate(WIDTHS):
-            g_lo, g_hi = off, off + w * m.n                    # live part of the group (rows beyond n are padding)
-            a, b = max(lo, g_lo), min(hi, g_hi)
-            if b > a:
-                out.append((gi, a, b - a))
+            out.append((gi, off, w * R))
             off += w * m.capacity
         return out
+
+    def _slice_pieces(self):
+        """This rank's part of the flat buffers as (group index, first float, count) pieces: its rows of every group, cut at
+        the live count (rows beyond n are alignment padding: exchanged, never updated)."""
+        m, G, r = self.model, self.ctx.world, self.ctx.rank
+        L = self._exchange_rows() // G
+        lo, hi = r * L, min((r + 1) * L, m.n)
+        if hi <= lo:
+            return []
+        return [(gi, off + w * lo, w * (hi - lo)) for (gi, off, _), w in zip(self._group_spans(), WIDTHS)]
 
     def _optimizer_step(self, n: int):
         if not self.ctx.active:
@@ -193,26 +206,31 @@ class DataParallelMixin:
             allreduce_mean_(self._live_grads(), self.ctx)
             return super()._optimizer_step(n)
         gflat = m.flat["g"]
-        reduce_scatter_sum_(gflat, self.ctx)
+        for _, off, cnt in self._group_spans():
+            reduce_scatter_sum_(gflat[off: off + cnt], self.ctx)
         pieces = self._slice_pieces()
         if pieces:
             lrs = self.lrs()
             P, M, V = m.flat["p"][m.cur], m.flat["m"][m.cur], m.flat["v"][m.cur]
             # the reduce-scatter delivered the SUM over the ranks; the mean's 1 / world is applied by the Adam kernel as it
             # reads the gradient (a separate mul_ over the slice was one more read and write of it per step)
-            gs = [gflat[a: a + cnt] for _, a, cnt in pieces]
-            ops.adam_step([P[a: a + cnt] for _, a, cnt in pieces], gs, [M[a: a + cnt] for _, a, cnt in pieces],
-                          [V[a: a + cnt] for _, a, cnt in pieces], [lrs[gi] for gi, _, _ in pieces], self.step_count + 1,
+            ops.adam_step([P[a: a + cnt] for _, a, cnt in pieces], [gflat[a: a + cnt] for _, a, cnt in pieces],
+                          [M[a: a + cnt] for _, a, cnt in pieces], [V[a: a + cnt] for _, a, cnt in pieces],
+                          [lrs[gi] for gi, _, _ in pieces], self.step_count + 1,
                           beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps, grad_scale=1.0 / self.ctx.world)
-        all_gather_slices_(m.flat["p"][m.cur], self.ctx)
+        P = m.flat["p"][m.cur]
+        for _, off, cnt in self._group_spans():
+            all_gather_slices_(P[off: off + cnt], self.ctx)
         self._moments_current = False
 
     def _sync_optimizer_state(self):
-        """Bring exp_avg / exp_avg_sq up to date on every rank (each keeps only its slice current between refines)."""
+        """Bring exp_avg / exp_avg_sq up to date on every rank (each keeps only its rows current between refines)."""
         if self.ctx.active and self.shard_optimizer and not self._moments_current:
             m = self.model
-            all_gather_slices_(m.flat["m"][m.cur], self.ctx)
-            all_gather_slices_(m.flat["v"][m.cur], self.ctx)
+            for k in ("m", "v"):
+                buf = m.flat[k][m.cur]
+                for _, off, cnt in self._group_spans():
+                    all_gather_slices_(buf[off: off + cnt], self.ctx)
             self._moments_current = True
 
     def xgmi_bytes_per_step(self) -> int:
@@ -221,7 +239,7 @@ class DataParallelMixin:
             return 0
         G, m = self.ctx.world, self.model
         if self.shard_optimizer:
-            return int(2 * (G - 1) / G * 4 * sum(WIDTHS) * m.capacity)
+            return int(2 * (G - 1) / G * 4 * sum(WIDTHS) * self._exchange_rows())
         return int(2 * 2 * (G - 1) / G * 4 * sum(WIDTHS) * m.n)           # ring all-reduce = reduce-scatter + all-gather of everything
 
     def _async_error_bits(self) -> int:

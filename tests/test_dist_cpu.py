@@ -161,6 +161,18 @@ def _sharded_worker(rank, world, port, q):
         tot = sum(trainer.WIDTHS) * A.model.capacity
         out["slice_elems"] = sum(c for _, _, c in pieces)
         n = A.model.n
+        # the work is cut by LIVE rows -- with n well below the capacity every rank still owns its share of every
+        # group (rows differ by at most one alignment unit of 4 * world), and only the live rows travel
+        cap0, n0 = A.model.capacity, A.model.n
+        A.model.n = n0 // 2
+        rows = [c // w for (_, _, c), w in zip(A._slice_pieces(), trainer.WIDTHS)]
+        allrows = [None] * world
+        dist.all_gather_object(allrows, rows)
+        per_rank = [r_[0] if r_ else 0 for r_ in allrows]
+        out["balanced"] = (all(len(r_) == 6 and len(set(r_)) == 1 for r_ in allrows if r_) and sum(per_rank) == n0 // 2
+                           and max(per_rank) - min(per_rank) <= 4 * world)
+        out["bytes_follow_live_rows"] = A.xgmi_bytes_per_step() < 0.6 * int(2 * (world - 1) / world * 4 * sum(trainer.WIDTHS) * cap0)
+        A.model.n = n0
         for step in range(3):
             g = torch.Generator().manual_seed(1000 * step + rank)             # every rank saw a different view
             for tr in (A, B):
@@ -221,6 +233,7 @@ def test_sharded_optimizer_equals_dense_all_reduce(world):
         assert "error" not in res[r], res[r].get("error")
         o = res[r]
         assert o["flat"] and o["same_as_dense"] and o["moved"] and o["in_sync"] and o["tiling"], o
+        assert o["balanced"] and o["bytes_follow_live_rows"], o
         assert o["moments_were_sharded"] and o["moments_after_sync"], o
         assert o["bytes"][0] > 0 and o["bytes"][1] > 0
 

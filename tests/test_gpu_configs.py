@@ -196,7 +196,8 @@ def test_full_size_binning_bit_exact_and_raster_properties(dev, kind, cam):
 
 @pytest.mark.parametrize("kind,cam,crops", [
     ("lego", 7, [(320, 336, 160, 96), (96, 400, 128, 64)]),
-    ("garden", 0, [(880, 560, 160, 96), (48, 640, 128, 64), (1776, 464, 144, 80)])])
+    ("garden", 0, [(880, 560, 160, 96), (48, 640, 128, 64), (1776, 464, 144, 80)]),
+    ("6m", 3, [(896, 592, 128, 64)])])
 def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
     """The float64 oracle can not run a 2 M-Gaussian 1080p frame in test time, but it can run WINDOWS of that
     frame: the same Gaussians, the same camera with its principal point shifted.  The HIP path runs the
@@ -207,8 +208,9 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         Kc = crop_camera(sc.Ks[cam:cam + 1], x0, y0)
         vm = sc.viewmats[cam:cam + 1]
         with torch.no_grad():       # the oracle's own cull decides which Gaussians its autograd pass has to carry
-            radii = O.projection(A["means"].double(), A["quats"].double(), A["scales"].double(), vm.double(), Kc.double(),
-                                 cw, ch, opacities=A["opacities"].double())[0]
+            proj64 = O.projection(A["means"].double(), A["quats"].double(), A["scales"].double(), vm.double(), Kc.double(),
+                                  cw, ch, opacities=A["opacities"].double())
+            radii = proj64[0]
         idx = torch.nonzero((radii > 0).all(-1)[0]).flatten()
         assert idx.numel() > 500
         g = torch.Generator().manual_seed(x0 + y0)
@@ -219,19 +221,33 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         r, a, gr, meta = _hip_fwd_bwd(A, vm, Kc, cw, ch, wr, wa, dev, bg=bg)
         _check_images(r, a, r_ref, a_ref, mean_tol=1e-4, q_tol=5e-3, max_tol=5e-2)
         assert a_ref.mean() > 0.05
+        # Two thousand splats deep, a handful of splats with near-equal depth sit at a DIFFERENT list position under float32
+        # depth keys than under the oracle's float64 depths.  Where two such splats overlap on screen, each sees the other's alpha
+        # in its transmittance or not, and everything in FRONT of them (same pixels) sees another colour behind it: a first-order
+        # difference for exactly those Gaussians and no others.  They are identified from the two depth orders and the screen
+        # boxes (not picked by their error, as round 2's "eight worst" were) and set aside; everything else is held to 2e-3.
+        sp32 = meta["splats"][0].cpu()[idx]
+        d32 = sp32[:, 9].contiguous().view(torch.int32).long()            # float32 depth > 0: the bit pattern orders like the value
+        d64 = proj64[2][0][idx]
+        pos32 = torch.empty_like(idx)
+        pos32[torch.argsort(d32 * (idx.max() + 1) + idx)] = torch.arange(idx.numel())      # (depth key, Gaussian index): the library's order
+        pos64 = torch.empty_like(idx)
+        pos64[torch.argsort(d64, stable=True)] = torch.arange(idx.numel())
+        moved = torch.nonzero(pos32 != pos64).flatten()
+        assert moved.numel() <= max(16, idx.numel() // 200), (kind, (x0, y0), "too many order differences", int(moved.numel()))
+        aside = torch.zeros(idx.numel(), dtype=torch.bool)
+        aside[moved] = True
+        rad = meta["radii"][0].cpu()[idx].double()
+        lo, hi = sp32[:, 0:2].double() - rad, sp32[:, 0:2].double() + rad
+        for m in moved.tolist():            # every splat at or in front of a moved one whose screen box overlaps it
+            ov = (lo[:, 0] < hi[m, 0]) & (hi[:, 0] > lo[m, 0]) & (lo[:, 1] < hi[m, 1]) & (hi[:, 1] > lo[m, 1])
+            aside |= ov & (pos64 <= max(int(pos64[m]), int(pos32[m])))
+        keep = ~aside
+        assert int(keep.sum()) > 0.5 * idx.numel(), (kind, (x0, y0), "exclusion swallowed the crop", int(aside.sum()), idx.numel())
         for k in ("means", "quats", "scales", "opacities", "sh"):
-            # Two thousand splats deep, a handful of pairs with near-equal depth sort differently by float32 and
-            # by float64 depth, and every splat behind such a pair sees a slightly different transmittance: in S2
-            # one 66 x 211 px splat alone carries 0.7 % of the quaternion-gradient norm that way (tools/diag_quats.py:
-            # the oracle rasteriser fed the HIP path's OWN projected records agrees with it to 1.7e-4).  So: a loose
-            # bound on everything, the tight one with the eight worst Gaussians set aside, and below the rasteriser
-            # alone on identical records.
             d = (gr[k][idx].double() - g_ref[k]).reshape(idx.numel(), -1)
-            worst = torch.topk(d.norm(dim=1), 8).indices
-            keep = torch.ones(idx.numel(), dtype=torch.bool)
-            keep[worst] = False
             e_all, e_rest = rel_err(gr[k][idx], g_ref[k]), float(d[keep].norm() / g_ref[k].reshape(idx.numel(), -1)[keep].norm())
-            assert e_all < 1e-2 and e_rest < 2e-3, (kind, (x0, y0), k, e_all, e_rest)
+            assert e_all < 1e-2 and e_rest < 2e-3, (kind, (x0, y0), k, e_all, e_rest, int(moved.numel()), int(aside.sum()))
             rest = gr[k].clone()
             rest[idx] = 0
             assert float(rest.norm()) <= 1e-3 * float(gr[k].norm()), (k, "gradient outside the oracle's visible set")

@@ -1,0 +1,99 @@
+"""Same-box A/B of rasterize_bwd (and rasterize_fwd) between builds of the library: same scene, same lists, the kernels of
+each build timed alternately with HIP events; results compared against the first build's.
+
+  python tools/raster_ab.py --libs pipeline-pointcloud_amd/mi3dgs/libmi3dgs.so tools/ab/libmi3dgs_r2.so [--scene garden] [--absgrad]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pipeline-pointcloud_amd"))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", nargs="+", required=True)
+    ap.add_argument("--scene", default="garden")
+    ap.add_argument("--cam", type=int, default=0)
+    ap.add_argument("--absgrad", action="store_true")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--modes", nargs="*", type=int, default=None, help="raster mode per lib (experiments builds), default 1")
+    a = ap.parse_args()
+    from mi3dgs import _lib, ops, scenes
+    dev = torch.device("cuda:0")
+    sc = scenes.make_scene(a.scene)
+    W, H = sc.width, sc.height
+    g = {k: v.to(dev) for k, v in sc.params.items()}
+    vm, K = sc.viewmats[a.cam:a.cam + 1].to(dev).contiguous(), sc.Ks[a.cam:a.cam + 1].to(dev).contiguous()
+    N = g["means"].shape[0]
+    radii, splats = ops.project_fwd(g["means"], g["quats"], g["scales"], g["opacities"], vm, K, W, H, sh0=g["sh0"], shN=g["shN"],
+                                    sh_degree=3, flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC)
+    b = ops.bin_tiles(radii, splats, W, H, 16, tight=True, radii_in_records=True)
+    bg = torch.tensor([[0.2, 0.3, 0.4]], device=dev)
+    r, al, last = ops.rasterize_fwd(splats, b, W, H, 16, bg, {})
+    gen = torch.Generator().manual_seed(3)
+    vr = (torch.rand(1, H, W, 3, generator=gen) - 0.5).to(dev)
+    va = (torch.rand(1, H, W, 1, generator=gen) - 0.5).to(dev)
+    st = ops._stream(dev)
+    handles = []
+    for i, path in enumerate(a.libs):
+        h = C.CDLL(os.path.abspath(path))
+        for name in ("mi3dgs_rasterize_bwd", "mi3dgs_rasterize_fwd", "mi3dgs_debug_set_raster_mode", "mi3dgs_last_error"):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = _lib._SIGNATURES[name]
+        if a.modes:
+            assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
+        handles.append(h)
+
+    def bwd(h, out):
+        out.zero_()
+        rc = h.mi3dgs_rasterize_bwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
+                                    ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last), ops._p(vr),
+                                    ops._p(va), int(a.absgrad), ops._p(out), st)
+        assert rc == 0, h.mi3dgs_last_error()
+
+    def fwd(h, o):
+        rc = h.mi3dgs_rasterize_fwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
+                                    ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(o[0]), ops._p(o[1]), ops._p(o[2]), st)
+        assert rc == 0, h.mi3dgs_last_error()
+
+    outs = [torch.zeros(1, N, 16, device=dev) for _ in handles]
+    fo = [(torch.empty_like(r), torch.empty_like(al), torch.empty_like(last)) for _ in handles]
+    tb = [[] for _ in handles]
+    tf = [[] for _ in handles]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(a.reps + 2):
+        for i, h in enumerate(handles):
+            for fn, arg, acc in ((bwd, outs[i], tb[i]), (fwd, fo[i], tf[i])):
+                if fn is bwd:
+                    arg.zero_()
+                e0.record()
+                if fn is bwd:
+                    rc = h.mi3dgs_rasterize_bwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
+                                                ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last),
+                                                ops._p(vr), ops._p(va), int(a.absgrad), ops._p(arg), st)
+                    assert rc == 0, h.mi3dgs_last_error()
+                else:
+                    fwd(h, arg)
+                e1.record()
+                e1.synchronize()
+                if rep >= 2:
+                    acc.append(e0.elapsed_time(e1) * 1e3)
+    res = []
+    ref = outs[0].double()
+    for i, path in enumerate(a.libs):
+        d = outs[i].double()
+        cols = 11 if a.absgrad else 9
+        err = float((d[..., :cols] - ref[..., :cols]).norm() / ref[..., :cols].norm())
+        res.append(dict(lib=path, mode=(a.modes[i] if a.modes else 1), bwd_us_median=sorted(tb[i])[len(tb[i]) // 2], bwd_us_min=min(tb[i]),
+                        fwd_us_median=sorted(tf[i])[len(tf[i]) // 2], rel_diff_vs_first=err,
+                        fwd_equal_first=bool(torch.equal(fo[i][0], fo[0][0]) and torch.equal(fo[i][2], fo[0][2]))))
+    print(json.dumps(dict(scene=a.scene, absgrad=a.absgrad, n_isect=int(b["n_isect"].item()), results=res), indent=1), flush=True)
+
+
+if __name__ == "__main__":
+    main()

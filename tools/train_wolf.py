@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--points", type=int, default=9000)
     ap.add_argument("--steps", type=int, default=7000)
     ap.add_argument("--model", default="splatfacto")
+    ap.add_argument("--mode", default="ns-train", choices=["ns-train", "simple_trainer"],
+                    help="simple_trainer: gsplat's launcher (main.py:1318-1347) with --strategy default|mcmc taken from --model")
     ap.add_argument("--backdrop", type=int, default=12_000,
                     help="Gaussians of an opaque, smoothly coloured shell around the wolf (radius 9 x its extent): every pixel shows "
                          "content, like a photograph in a room (0 = none: constant background 0.15, the round-2 dataset)")
@@ -78,14 +80,23 @@ def main():
     a.points = sel.numel()
     xyz = (P["means"][sel] + 0.002 * ext * torch.randn(a.points, 3)).double().numpy()
     rgb = ((0.5 + 0.2820948 * P["sh0"][sel, 0]).clamp(0, 1) * 255).byte().numpy()
-    io_colmap.write_model(os.path.join(root, "colmap", "sparse", "0"), cams, ims, xyz, rgb)
+    sparse = os.path.join(root, "colmap", "sparse", "0") if a.mode == "ns-train" else os.path.join(root, "sparse", "0")
+    io_colmap.write_model(sparse, cams, ims, xyz, rgb)
     del tr
     torch.cuda.empty_cache()
-    print(f"[wolf] target: {n} Gaussians of the reference's wolf.spz (real SH, extent {ext:.3f}); {a.views} views "
+    print(f"[wolf] target: {n} Gaussians of the reference's wolf.spz (real SH, extent {ext:.3f}) + backdrop; {a.views} views "
           f"{a.width}x{a.height} u8 PNG, object covers {100 * sum(cover) / len(cover):.0f} % of a frame; "
           f"{a.points} of {n} points (jittered) as the SfM cloud", flush=True)
     os.chdir(root)
     t0 = time.time()
+    if a.mode == "simple_trainer":
+        res = os.path.join(root, "exports")
+        strat = "mcmc" if a.model.endswith("mcmc") else "default"
+        cli.main_simple_trainer([strat, "--max_steps", str(a.steps), "--result-dir", res, "--data_factor", "1", "--steps_scaler", "1.0",
+                                 "--disable_viewer", "--packed", "--batch-size", "1", "--data-dir", root] + extra)
+        st = json.load(open(os.path.join(res, "stats", f"val_step{a.steps - 1:04d}.json")))
+        print(f"[wolf] result: {json.dumps(st)} (simple_trainer.py {strat}) in {time.time() - t0:.1f}s wall", flush=True)
+        return
     cli.main_ns_train([a.model, "--timestamp", "train-stage-1", "--viewer.quit-on-train-completion=True",
                        "--logging.local-writer.enable", "False", "--logging.profiler", "none",
                        "--pipeline.model.use_scale_regularization=True", "--max-num-iterations", str(a.steps)] + extra +
