@@ -1351,10 +1351,17 @@ __global__ __launch_bounds__(64 * WE_WAVES) void tile_emit_wave_kernel(
         if (owns) {
             idx = sorted_ids[i];
             const float* sp = splats + (size_t)idx * SPLAT_STRIDE;
+            // the geometry is requested together with the radii, not behind the test of them: the record is one 64-byte line,
+            // and as "radii -> wait -> branch -> geometry -> wait" the gather was three dependent round trips instead of two
+            // (tools: the ISA scan of round 3, serial load -> s_waitcnt vmcnt(0) chains)
+            const float4 g0 = *reinterpret_cast<const float4*>(sp);              // x y A B
+            const float2 g1 = *reinterpret_cast<const float2*>(sp + SP_CC);      // C o
             int2 r = radii_in_records ? make_int2(__float_as_int(sp[SP_RX]), __float_as_int(sp[SP_RY]))
                                       : *reinterpret_cast<const int2*>(radii + 2 * (size_t)idx);
+            asm volatile("" :: "v"(g0.x), "v"(g1.x), "v"(r.x));          // (keeps the three loads in front of the branch: hipcc sinks them into it)
             if (r.x > 0 && r.y > 0) {
-                geo = span_geom(sp, r, tile_size, tw, th);
+                const float rec6[6] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y};      // SP_X .. SP_OPA
+                geo = span_geom(rec6, r, tile_size, tw, th);
                 rows = (uint32_t)(geo.y1 - geo.y0);
                 kc = (idx / N) * (uint32_t)(tw * th);
             }

@@ -530,6 +530,9 @@ __device__ __forceinline__ void slice_load(float* lds, const float* src, int cou
     float4 tmp[(SH_WAVE_F4 + 63) / 64];
 #pragma unroll
     for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) tmp[j] = s4[min(lane + 64 * j, max(n4 - 1, 0))];   // all loads in flight
+    // (the clobber keeps the twelve loads in FRONT of the LDS stores: without it hipcc pairs each load with its store again,
+    //  load -> s_waitcnt vmcnt(0) -> ds_write twelve times in a row, in the unfused backward the MCMC and data-parallel trainers run)
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < (SH_WAVE_F4 + 63) / 64; j++) {
         int i4 = lane + 64 * j;

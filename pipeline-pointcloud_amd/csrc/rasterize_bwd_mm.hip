@@ -331,10 +331,23 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
     RB_STAMP(2, (unsigned long long)(bmax - start + 1));
     const Basis basis = make_basis(wv, lane);
 
-    // the B operands of the contraction and this lane's place in its result
+    // the B operands of the contraction and this lane's place in its result.
+    // The v_rgb part of B (columns 6..11) needs, per lane, one colour channel of SIXTEEN of the wave's pixels -- values the
+    // pixel-owner lanes already hold (vr0..2: lane l owns pixel l of the quadrant).  They go through the wave's transposition
+    // rows (free until the first visit): three stores, sixteen reads.  Until round 3 every lane fetched them from v_render
+    // itself, and the bounds test around each fetch compiled to load -> s_waitcnt vmcnt(0) sixteen times in a row: sixteen
+    // dependent memory round trips at the head of every block's life, most of the ~15 us fixed cost per block (and the reason
+    // rasterize_bwd was 37 % of a real training step whose tiles hold ~70 splats each).
     MMLane mm;
     {
         const int j = lane & 15, g = lane >> 4;
+        L.tr[wv][0][lane] = __builtin_bit_cast(unsigned, vr0);
+        L.tr[wv][1][lane] = __builtin_bit_cast(unsigned, vr1);
+        L.tr[wv][2][lane] = __builtin_bit_cast(unsigned, vr2);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // same-wave LDS hand-off
+        __builtin_amdgcn_wave_barrier();
+        const int cch = j < 9 ? j - 6 : j - 9;                      // colour channel of columns 6..11 (others: unused)
+        const unsigned* vrow = &L.tr[wv][(cch >= 0 && cch < 3) ? cch : 0][4 * g];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             u4v w;
@@ -343,15 +356,12 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
                 int qx, qy;
                 pixel_of_lane(wv, 16 * m + 4 * g + e, qx, qy);
                 const float u = (float)qx - 7.5f, v = (float)qy - 7.5f;
+                const float val = __builtin_bit_cast(float, vrow[16 * m + e]);      // v_rgb[cch] of pixel 16 m + 4 g + e (0 outside the image)
                 unsigned hb = 0u;                  // bf16 bits
                 if (j < 6) {
-                    const float val = j == 0 ? u : j == 1 ? v : j == 2 ? u * u : j == 3 ? u * v : j == 4 ? v * v : 1.f;
-                    hb = __builtin_bit_cast(unsigned, val) >> 16;          // exact
+                    const float bv = j == 0 ? u : j == 1 ? v : j == 2 ? u * u : j == 3 ? u * v : j == 4 ? v * v : 1.f;
+                    hb = __builtin_bit_cast(unsigned, bv) >> 16;          // exact
                 } else if (j < 12) {
-                    const int c = j < 9 ? j - 6 : j - 9;
-                    const int gx = tx * TILE + qx, gy = ty * TILE + qy;
-                    float val = 0.f;
-                    if (gx < W && gy < H) val = v_render[3 * (((size_t)cam * H + gy) * W + gx) + c];
                     const unsigned hi = f32_hi(val);
                     if (j < 9) hb = hi >> 16;
                     else {
@@ -363,6 +373,8 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
             }
             mm.bop[m] = w;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the rows are rewritten by the first chunk
+        __builtin_amdgcn_wave_barrier();
         // columns of the product: 0..5 moments (AC_QU .. AC_Q), 6..8 colour sums from the hi part of v_rgb, 9..11 from its lo part
         if (ABSGRAD) {
             // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3

@@ -234,20 +234,29 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         pos64 = torch.empty_like(idx)
         pos64[torch.argsort(d64, stable=True)] = torch.arange(idx.numel())
         moved = torch.nonzero(pos32 != pos64).flatten()
-        assert moved.numel() <= max(16, idx.numel() // 200), (kind, (x0, y0), "too many order differences", int(moved.numel()))
+        assert moved.numel() <= max(16, idx.numel() // 50), (kind, (x0, y0), "too many order differences", int(moved.numel()))
         aside = torch.zeros(idx.numel(), dtype=torch.bool)
-        aside[moved] = True
         rad = meta["radii"][0].cpu()[idx].double()
         lo, hi = sp32[:, 0:2].double() - rad, sp32[:, 0:2].double() + rad
-        for m in moved.tolist():            # every splat at or in front of a moved one whose screen box overlaps it
-            ov = (lo[:, 0] < hi[m, 0]) & (hi[:, 0] > lo[m, 0]) & (lo[:, 1] < hi[m, 1]) & (hi[:, 1] > lo[m, 1])
-            aside |= ov & (pos64 <= max(int(pos64[m]), int(pos32[m])))
+        n_pairs = 0
+        for m in moved.tolist():
+            # the splats whose order relative to m differs between the two sorts (normally one neighbour), where their screen
+            # boxes overlap: there m and its partner see each other's alpha or not, and every splat in front that reaches into
+            # that overlap sees another colour behind it
+            part = moved[(torch.sign(pos32[moved] - pos32[m]) != torch.sign(pos64[moved] - pos64[m]))]
+            for j in part.tolist():
+                rlo, rhi = torch.maximum(lo[m], lo[j]), torch.minimum(hi[m], hi[j])
+                if bool((rlo < rhi).all()):
+                    n_pairs += 1
+                    aside[m] = aside[j] = True
+                    ov = (lo[:, 0] < rhi[0]) & (hi[:, 0] > rlo[0]) & (lo[:, 1] < rhi[1]) & (hi[:, 1] > rlo[1])
+                    aside |= ov & (pos64 < min(int(pos64[m]), int(pos64[j])))
         keep = ~aside
-        assert int(keep.sum()) > 0.5 * idx.numel(), (kind, (x0, y0), "exclusion swallowed the crop", int(aside.sum()), idx.numel())
+        assert int(keep.sum()) > 0.8 * idx.numel(), (kind, (x0, y0), "exclusion swallowed the crop", int(aside.sum()), idx.numel(), n_pairs)
         for k in ("means", "quats", "scales", "opacities", "sh"):
             d = (gr[k][idx].double() - g_ref[k]).reshape(idx.numel(), -1)
             e_all, e_rest = rel_err(gr[k][idx], g_ref[k]), float(d[keep].norm() / g_ref[k].reshape(idx.numel(), -1)[keep].norm())
-            assert e_all < 1e-2 and e_rest < 2e-3, (kind, (x0, y0), k, e_all, e_rest, int(moved.numel()), int(aside.sum()))
+            assert e_all < 1e-2 and e_rest < 2e-3, (kind, (x0, y0), k, e_all, e_rest, int(moved.numel()), n_pairs, int(aside.sum()))
             rest = gr[k].clone()
             rest[idx] = 0
             assert float(rest.norm()) <= 1e-3 * float(gr[k].norm()), (k, "gradient outside the oracle's visible set")

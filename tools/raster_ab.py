@@ -25,7 +25,19 @@ def main():
     a = ap.parse_args()
     from mi3dgs import _lib, ops, scenes
     dev = torch.device("cuda:0")
-    sc = scenes.make_scene(a.scene)
+    if a.scene == "wolf":        # the real-training regime: the reference's wolf.spz + backdrop at 960 x 720 (tools/train_wolf.py)
+        import math
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import load_wolf
+        P = load_wolf()
+        centre = P["means"].median(0).values
+        ext = float((P["means"] - centre).abs().quantile(0.99))
+        P = scenes.add_backdrop(scenes.Scene("wolf", P, None, None, 960, 720), 12000, 9.0 * ext, tuple(centre.tolist())).params
+        eye = centre + torch.tensor([3.2 * ext * math.cos(0.6) * math.cos(0.3), -3.2 * ext * math.sin(0.3), 3.2 * ext * math.sin(0.6) * math.cos(0.3)])
+        sc = scenes.Scene("wolf", P, scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0))[None], scenes._intrinsics(1.25 * 960, 960, 720)[None], 960, 720)
+        a.cam = 0
+    else:
+        sc = scenes.make_scene(a.scene)
     W, H = sc.width, sc.height
     g = {k: v.to(dev) for k, v in sc.params.items()}
     vm, K = sc.viewmats[a.cam:a.cam + 1].to(dev).contiguous(), sc.Ks[a.cam:a.cam + 1].to(dev).contiguous()
@@ -71,6 +83,8 @@ def main():
             for fn, arg, acc in ((bwd, outs[i], tb[i]), (fwd, fo[i], tf[i])):
                 if fn is bwd:
                     arg.zero_()
+                if a.modes:      # (the same library loaded twice is ONE handle with one mode word: set it for every launch)
+                    assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
                 e0.record()
                 if fn is bwd:
                     rc = h.mi3dgs_rasterize_bwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--strategy", default="default", choices=["default", "mcmc"])
     ap.add_argument("--keep", default=None, help="directory to keep the dataset and outputs in")
     ap.add_argument("--seed-noise", type=float, default=0.01, help="jitter of the SfM-like seed points")
+    ap.add_argument("--model-big", action="store_true", help="ns-train mode: splatfacto-big instead of splatfacto")
+    ap.add_argument("--random-colours", action="store_true", help="keep the generator's independent random colour per Gaussian")
     ap.add_argument("--backdrop", type=int, default=20_000,
                     help="Gaussians of an opaque shell (radius 25) around the scene, so that every pixel shows content like a "
                          "photograph (0 = none: uncovered pixels then carry the constant background 0.2, the round-1/2 dataset)")
@@ -43,6 +45,17 @@ def main():
     sc = scenes.make_garden_like(n=a.gt, seed=7, width=a.width, height=a.height, n_views=a.views,
                                  fx=1450.0 * a.width / 1920.0)
     sc.params["opacities"] += 1.5                          # a mostly opaque scene, like a trained one
+    if not a.random_colours:
+        # colours that vary smoothly in space, like surfaces do: the bench generator draws every Gaussian's colour independently,
+        # a 200 k-splat noise field that no 20 k-point reconstruction can represent (default strategy stuck at 29 - 30 dB, the MCMC
+        # strategy's photometric gradients average out and its opacity regulariser empties the scene: profiles/r03_train_30000.txt)
+        m = sc.params["means"]
+        rgb = 0.5 + 0.35 * torch.stack([torch.sin(1.3 * m[:, 0] + 0.5) * torch.cos(0.9 * m[:, 1]),
+                                        torch.sin(1.1 * m[:, 1] + 1.0) * torch.cos(1.7 * m[:, 2] + 0.6 * m[:, 0]),
+                                        torch.sin(0.7 * m[:, 0] - 1.2 * m[:, 1])], dim=-1)
+        rgb = rgb + 0.04 * torch.randn(rgb.shape, generator=torch.Generator().manual_seed(5))
+        sc.params["sh0"] = ((rgb - 0.5) / 0.28209479)[:, None, :].contiguous()
+        sc.params["shN"] = sc.params["shN"] * 0.3
     sc.params["scales"] += np.log(2.5 * (2_000_000 / a.gt) ** (1 / 3))   # keep the surface covered at lower counts
     n_obj = a.gt
     if a.backdrop > 0:
@@ -82,7 +95,7 @@ def main():
         st = json.load(open(os.path.join(res, "stats", f"val_step{a.steps - 1:04d}.json")))
     else:
         os.chdir(root)
-        model = "splatfacto-mcmc" if a.strategy == "mcmc" else "splatfacto"
+        model = "splatfacto-mcmc" if a.strategy == "mcmc" else ("splatfacto-big" if a.model_big else "splatfacto")
         cli.main_ns_train([model, "--timestamp", "train-stage-1", "--pipeline.model.use_scale_regularization=True",
                            "--max-num-iterations", str(a.steps)] + extra + ["colmap", "--data", root, "--downscale-factor", "1"])
         st = json.loads("".join(l for l in open("outputs/unnamed/splatfacto/train-stage-1/config.yml") if not l.startswith("#")))["stats"]
