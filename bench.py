@@ -197,12 +197,26 @@ def cpu_baseline_cpu_tensors(P, vm, K, gt, W, H, crop_div=6):
     t0 = time.perf_counter()
     torch.autograd.backward([m2d, con, cols, op], [rin[0].grad, rin[1].grad, rin[2].grad, rin[3].grad[0]])
     tC = time.perf_counter() - t0
-    full = tA + tC + crop_div * crop_div * tB
-    return dict(value=1.0 / full, unit="it/s", cores=threads, kind="port",
-                sample=f"oracle/gs_oracle.py float32, one train step: project+SH over all {N} Gaussians fwd {tA:.2f} s "
-                       f"+ bwd {tC:.2f} s, and binning+rasterise+loss fwd/bwd on a {cw}x{ch} centre crop "
-                       f"({ids.numel()} intersections) {tB:.2f} s; extrapolated full frame = A + C + {crop_div**2} x B "
-                       f"= {full:.1f} s; Adam not included")
+    # D: the Adam step over all six groups (the oracle's own update rule, torch.optim.Adam arithmetic, eps 1e-15)
+    t0 = time.perf_counter()
+    for k, v in leaves.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        O.adam_step(v.detach(), g, torch.zeros_like(v), torch.zeros_like(v), 1, 1e-3)
+    tD = time.perf_counter() - t0
+    full = tA + tC + tD + crop_div * crop_div * tB
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=1.0 / full, unit="it/s", cores=threads, kind="port", cpu_model=cpu_model,
+                sample=f"oracle/gs_oracle.py float32 on {threads} threads of {cpu_model}, one train step: project+SH over all {N} "
+                       f"Gaussians fwd {tA:.2f} s + bwd {tC:.2f} s, Adam over all parameters {tD:.2f} s, and binning+rasterise+loss "
+                       f"fwd/bwd on a {cw}x{ch} centre crop ({ids.numel()} intersections) {tB:.2f} s; extrapolated full frame "
+                       f"= A + C + D + {crop_div**2} x B = {full:.1f} s")
 
 
 def box_info() -> dict:

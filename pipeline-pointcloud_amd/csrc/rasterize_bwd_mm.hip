@@ -32,20 +32,42 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int TR_STRIDE = 68;
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
-// Splats per staged batch = one per thread.  Round 3 measured 128 (LDS 39.7 KB, room for four blocks per CU) with the kernel
-// held to 128 VGPRs for four waves per SIMD: 39 registers spilled to scratch, 515 us against 477 us on S2 and 169 against 147 us
-// on S1; the same 128-slot batches at three waves per SIMD 486 / 152 us (profiles/r03_raster_bwd_occupancy_ab.txt).  The fourth
-// wave has to come from ~40 fewer registers, not from the compiler's spiller.
-constexpr int STG = BLOCK;
-// columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums, then |x|, |y|
-constexpr int AW_ABSX = 12, AW_ABSY = 13;       // 9..11: the lo colour sums
+// ---- shape of the kernel (compile-time; the Makefile's BWD_SHAPE overrides them for same-box A/B builds, tools/raster_ab.py).
+//   MI_BWD_STG        splats per staged batch: 256 (one per thread) or 128 (LDS 50 -> 40 KB: room for four blocks per CU)
+//   MI_BWD_PIPELINE   1: a chunk's contraction is issued one MFMA per visit among the NEXT chunk's visits (16 + 4 more live
+//                     registers); 0: operands are read and the four MFMAs issued when the chunk ends
+//   MI_BWD_COL_AHEAD  the wave-uniform colour read runs this many visits ahead (3 registers each)
+//   MI_BWD_WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128)
+// Round 3 measured (profiles/r03_raster_bwd_occupancy_ab.txt): 128-slot batches with the pipelined contraction held to 128
+// VGPRs spill 39 registers and LOSE 8 % (S2) / 15 % (S1); without the pipelining and with the colour one visit ahead the
+// kernel needs 126 registers, no spills, four waves per SIMD.
+#ifndef MI_BWD_STG
+#define MI_BWD_STG 256
+#endif
+#ifndef MI_BWD_PIPELINE
+#define MI_BWD_PIPELINE 1
+#endif
+#ifndef MI_BWD_COL_AHEAD
+#define MI_BWD_COL_AHEAD 2
+#endif
+#ifndef MI_BWD_WAVES
+#define MI_BWD_WAVES 3
+#endif
+constexpr int STG = MI_BWD_STG;
+static_assert(STG == 128 || STG == 256, "MI_BWD_STG");
+// columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums (9..11; the flush adds
+// them), then |x|, |y|.  ABS_MERGE (ABSGRAD at four waves per SIMD, where the LDS has to stay under 40 KB): the lo colour sums
+// are added to the hi ones before they are stored (three lanes of the accumulator, one DPP shift each) and |x|, |y| take
+// columns 9, 10: eleven columns instead of fourteen.
+constexpr bool ABS_MERGE = MI_BWD_WAVES >= 4;
+constexpr int AW_ABSX = ABS_MERGE ? 9 : 12, AW_ABSY = ABS_MERGE ? 10 : 13;
 
 // LDS float atomics are lane-serial on this part (tools/micro/lds_ops.hip: ds_add_f32 takes ~3 LDS cycles per ACTIVE lane,
 // 55 for the 18 lanes that would add a chunk's sums, against 3 for a plain ds_write_b32), so every wave keeps its own sums
 // (plain stores, each (wave, slot, column) written at most once per group) and the flush adds the four quadrants.
 template <bool ABSGRAD>
 struct StagedBwdMM {
-    static constexpr int AW = ABSGRAD ? 14 : 12;
+    static constexpr int AW = ABSGRAD ? (ABS_MERGE ? 11 : 14) : 12;
     StagedN<STG> f;
     float4 geo[STG];          // mx, my (relative to the tile centre), A, B
     float2 geo2[STG];         // C, 1 / o
@@ -117,6 +139,14 @@ __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, co
 #pragma unroll
         for (int r = 0; r < 4; r++) P.d[r] += __shfl_down(P.d[r], 32, 64);
     }
+    if (ABSGRAD && ABS_MERGE) {     // colour sums: column j + 3 (from the lo part of v_rgb) onto column j = 6..8 (row_shl:3 inside the 16-lane row)
+        const bool col = (lane & 15) >= 6 && (lane & 15) < 9;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P.d[r]), 0x103, 0xF, 0xF, true));
+            P.d[r] += col ? up : 0.f;
+        }
+    }
     if (mm.acc_off >= 0) {
         float* a = &L.accw[wv][WF ? 0 : P.slot0][0] + mm.acc_off;
         a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3];
@@ -145,7 +175,7 @@ __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, co
                     case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + ac[AC_QUV]); break;
                     case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + ac[AC_QVV]); break;
                     case GR_OPA: val = M * g2.y; break;
-                    case GR_R: case GR_G: case GR_B: val = ac[comp] + ac[comp + 3]; break;
+                    case GR_R: case GR_G: case GR_B: val = (ABSGRAD && ABS_MERGE) ? ac[comp] : ac[comp] + ac[comp + 3]; break;
                     case GR_ABSX: val = ac[AW_ABSX < AW ? AW_ABSX : 0]; break;
                     default: val = ac[AW_ABSY < AW ? AW_ABSY : 0]; break;
                 }
@@ -189,7 +219,7 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
     // colours two visits ahead: LDS serves a wave in order, so a read queues behind the two stores of the visit before it
-    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, 1);
+    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, MI_BWD_COL_AHEAD == 2 ? 1 : 0);
     unsigned* trw = &L.tr[wv][0][lane];
     // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
     // bookkeeping counts like vector work.  A dead visit is a compare and a branch: its rows keep whatever they held, the
@@ -201,8 +231,11 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
         const int k = sb * SUB + i;
         const int ci = i % CH;
         const Rgb col = (EXP & 2) ? Rgb{0.3f, 0.4f, 0.5f} : col_next;
-        if (!(EXP & 2)) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
-        if (ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
+        if (!(EXP & 2)) {
+            if (MI_BWD_COL_AHEAD == 2) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
+            else col_next = lds_rgb(uni, i + 1);
+        }
+        if (MI_BWD_PIPELINE && ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
         // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
         unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
         if (!FAST) valid &= mask_ge_i(bin_final, be - k);
@@ -244,12 +277,13 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
             }
         }
         if (ci == CH - 1) {
-            if (P.on) mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
+            if (MI_BWD_PIPELINE && P.on) mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
             const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
             if (cl) {
                 mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
                 P.slot_abs = k - (CH - 1);
                 P.live = cl;
+                if (!MI_BWD_PIPELINE) mm_drain<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);      // read, four MFMAs, store: nothing stays live
             }
         }
     }
@@ -270,7 +304,7 @@ namespace mfma_raster {
 #endif
 
 template <bool HAS_BG, bool ABSGRAD, int EXP>
-__global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WAVES, MI_BWD_WAVES))) void rasterize_bwd_mm_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
         // columns of the product: 0..5 moments (AC_QU .. AC_Q), 6..8 colour sums from the hi part of v_rgb, 9..11 from its lo part
         if (ABSGRAD) {
             // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3
-            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : (j == 5 ? (g == 2 ? AW_ABSX : AW_ABSY) : -1);
+            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < (ABS_MERGE ? 9 : 12) ? j : -1) : (j == 5 ? (g == 2 ? AW_ABSX : AW_ABSY) : -1);
         } else if ((EXP & 8) != 0) {
             // three terms: rows Q 0..3, W 4..7 (words hi | mid), Q 8..11, W 12..15 (words lo | 0); groups 2, 3 are added to 0, 1 in mm_finish
             mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : -1;
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
                     const float M = __shfl(sum, rb + AC_Q, 64), Mu = __shfl(sum, rb + AC_QU, 64), Mv = __shfl(sum, rb + AC_QV, 64);
                     // second operand by output component: x, y none; conic A, B, C their second moments; r, g, b the lo sums
                     const int xsrc = comp == GR_CA ? AC_QUU : comp == GR_CB ? AC_QUV : comp == GR_CC ? AC_QVV
-                                     : (comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AW_ABSX : comp == GR_ABSY ? AW_ABSY : 0;
+                                     : (!(ABSGRAD && ABS_MERGE) && comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AW_ABSX : comp == GR_ABSY ? AW_ABSY : 0;
                     const float X = __shfl(sum, rb + xsrc, 64);
                     if (slot < bsz && touched && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
                         const float4 ge = L.geo[slot];
@@ -468,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_mm_kernel(
                             case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + X); break;
                             case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + X); break;
                             case GR_OPA: val = M * g2.y; break;
-                            case GR_R: case GR_G: case GR_B: val = sum + X; break;
+                            case GR_R: case GR_G: case GR_B: val = (ABSGRAD && ABS_MERGE) ? sum : sum + X; break;
                             default: val = X; break;          // |x|, |y|
                         }
                         atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);

@@ -296,3 +296,60 @@ def test_colmap_to_json_shim_writes_transforms_and_point_cloud(tmp_path, capsys)
                           ims, xyz, rgb)
     with pytest.raises(RuntimeError, match="Only single camera"):
         colmap_json.main(["-d", str(tmp_path / "two")])
+
+
+def test_colmap_reader_against_bytes_laid_out_from_the_published_format(tmp_path):
+    """the reader had only ever read files written by this repository's own writer.  Here the three
+    files are laid out byte by byte from COLMAP's documented binary format (src/colmap/scene/reconstruction_io.cc:
+    little-endian; cameras: u64 count, then per camera i32 id, i32 model, u64 width, u64 height, f64 params[];
+    images: u64 count, then per image i32 id, f64 qvec[4], f64 tvec[3], i32 camera_id, NUL-terminated name, u64 n_points2D,
+    n x (f64 x, f64 y, i64 point3D_id); points3D: u64 count, then per point u64 id, f64 xyz[3], u8 rgb[3], f64 error,
+    u64 track_length, track x (i32 image_id, i32 point2D_idx)) -- with several camera models, observations and tracks of
+    different lengths, i.e. records of different sizes that a reader has to step over correctly."""
+    import struct
+    from mi3dgs import io_colmap
+    d = tmp_path / "sparse" / "0"
+    d.mkdir(parents=True)
+    cams = [(7, 1, 1920, 1080, [1450.0, 1440.0, 960.0, 540.0]),                     # PINHOLE
+            (3, 2, 800, 600, [700.0, 400.0, 300.0, -0.05]),                         # SIMPLE_RADIAL
+            (11, 4, 640, 480, [500.0, 501.0, 320.0, 240.0, 0.1, -0.02, 1e-3, -2e-3])]   # OPENCV
+    b = struct.pack("<Q", len(cams))
+    for cid, model, w, h, p in cams:
+        b += struct.pack("<iiQQ", cid, model, w, h) + struct.pack(f"<{len(p)}d", *p)
+    (d / "cameras.bin").write_bytes(b)
+    imgs = [(5, (0.5, 0.5, -0.5, 0.5), (0.1, -0.2, 3.0), 7, "a/frame_0005.png", [(10.5, 20.25, 42), (1.0, 2.0, -1)]),
+            (2, (1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 3, "b.jpg", []),
+            (9, (0.0, 0.0, 1.0, 0.0), (-1.5, 2.5, 0.5), 11, "c with space.JPG", [(0.0, 0.0, 7)] * 5)]
+    b = struct.pack("<Q", len(imgs))
+    for iid, q, t, cid, name, obs in imgs:
+        b += struct.pack("<i4d3di", iid, *q, *t, cid) + name.encode() + b"\x00" + struct.pack("<Q", len(obs))
+        for x, y, pid in obs:
+            b += struct.pack("<ddq", x, y, pid)
+    (d / "images.bin").write_bytes(b)
+    pts = [(42, (1.0, 2.0, 3.0), (255, 0, 7), 0.5, [(5, 0), (9, 3)]),
+           (7, (-4.5, 0.25, 1e-3), (1, 2, 3), 1.25, [(9, 0)]),
+           (100000000000, (0.0, 0.0, 0.0), (128, 128, 128), 0.0, [])]
+    b = struct.pack("<Q", len(pts))
+    for pid, xyz, rgb, err, track in pts:
+        b += struct.pack("<Q3d3BdQ", pid, *xyz, *rgb, err, len(track))
+        for iid, k in track:
+            b += struct.pack("<ii", iid, k)
+    (d / "points3D.bin").write_bytes(b)
+
+    assert io_colmap.read_points3d_count(str(d / "points3D.bin")) == 3          # main.py:406-417
+    C = io_colmap.read_cameras(str(d / "cameras.bin"))
+    assert sorted(C) == [3, 7, 11]
+    assert (C[7].model, C[7].width, C[7].height) == ("PINHOLE", 1920, 1080) and C[7].pinhole() == (1450.0, 1440.0, 960.0, 540.0)
+    assert C[3].model == "SIMPLE_RADIAL" and C[3].pinhole() == (700.0, 700.0, 400.0, 300.0) and C[3].distortion().tolist() == [-0.05]
+    assert C[11].model == "OPENCV" and C[11].distortion().tolist() == [0.1, -0.02, 1e-3, -2e-3]
+    I = io_colmap.read_images(str(d / "images.bin"))
+    assert sorted(I) == [2, 5, 9]
+    assert I[5].name == "a/frame_0005.png" and I[5].camera_id == 7 and I[5].qvec.tolist() == [0.5, 0.5, -0.5, 0.5]
+    assert I[5].tvec.tolist() == [0.1, -0.2, 3.0]
+    assert I[2].name == "b.jpg" and I[9].name == "c with space.JPG" and I[9].camera_id == 11 and I[9].tvec.tolist() == [-1.5, 2.5, 0.5]
+    W = I[5].world_to_camera()
+    import numpy as np
+    assert np.allclose(W[:3, :3] @ W[:3, :3].T, np.eye(3), atol=1e-12) and np.allclose(W[:3, 3], [0.1, -0.2, 3.0])
+    xyz, rgb, err = io_colmap.read_points3d(str(d / "points3D.bin"))
+    assert xyz.tolist() == [[1.0, 2.0, 3.0], [-4.5, 0.25, 1e-3], [0.0, 0.0, 0.0]]
+    assert rgb.tolist() == [[255, 0, 7], [1, 2, 3], [128, 128, 128]] and err.tolist() == [0.5, 1.25, 0.0]
