@@ -54,6 +54,7 @@ extern "C" {
  *   MI3DGS_OS_MAX_KEYS        sorts above this many keys use the classic radix passes (default 4 M)
  *   MI3DGS_EMIT_SMALL_SPLATS  up to this many Gaussians the tile emit gives a wave 16 splats instead of 64 (default 128 K)
  *   MI3DGS_KEYS16=0           never sort 16-bit tile keys
+ *   MI3DGS_BWD_WIDE_MIN       from this many Gaussians on, rasterize_bwd runs its four-waves-per-SIMD shape (default 200 000)
  * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
  * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);
@@ -201,11 +202,13 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
                          const int32_t* flatten_ids, const int32_t* n_isect_dev,
                          const float* backgrounds, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, int absgrad, float* v_splats,
+                         long long n_gaussians /* rows of `splats` per camera: picks the kernel shape (0 = unknown) */,
                          void* stream);
 
 /* Product library: accepts 1 (the MFMA rasterisers, the only ones it holds) and fails for anything else.  Experiments
  * library: 0 = round-1 all-VALU kernels, 3 = f32 reduce-scatter backward, 4 = three-term bf16 backward, 14 = wave-flush
- * backward, 11..13 = timing experiments with wrong results (csrc/rasterize.hip). */
+ * backward, 21 / 22 = the product backward forced to its DEEP / WIDE shape, 11..13 = timing experiments with wrong results
+ * (csrc/rasterize.hip). */
 int mi3dgs_debug_set_raster_mode(int mode);
 
 /* ---- loss ----------------------------------------------------------------------------

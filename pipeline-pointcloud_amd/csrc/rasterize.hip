@@ -323,16 +323,18 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int variant, hipStream_t st);
+                          const float* v_alphas, int absgrad, float* v_splats, int variant, long long n_gauss, hipStream_t st);
 static int g_raster_mode = 1;
 // Mode 1 = the product kernels, the only mode the product library has.  The experiments build (libmi3dgs_exp.so) adds:
 // 0 = round-1 VALU kernels; 3 = MFMA forward + backward with the all-f32 cross-lane reduce-scatter instead of the bf16 MFMA
 // contraction (correct; the f32 yardstick of tests/test_gpu_configs.py); 4 = backward with THREE-term bf16 pixel sums
-// (24 significant bits; the A/B of VERDICT r2 #3); 14 = wave-flush backward (correct, slower); 11..13 = timing experiments
-// with WRONG results (no group flush / constant colours).  Forward and backward must run in the same mode.
+// (24 significant bits; the A/B of VERDICT r2 #3); 14 = wave-flush backward (correct, slower); 21 / 22 = the product backward
+// forced to its DEEP / WIDE shape; 11..13 = timing experiments with WRONG results (no group flush / constant colours).
+// Forward and backward must run in the same mode.
 extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
 #ifdef MI3DGS_EXPERIMENTS
-    MI_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 4 || (mode >= 11 && mode <= 14), "set_raster_mode: unknown mode");
+    MI_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 4 || (mode >= 11 && mode <= 14) || mode == 21 || mode == 22,
+               "set_raster_mode: unknown mode");
     g_raster_mode = mode;
     return 0;
 #else
@@ -373,7 +375,7 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
                                     const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                                     const int32_t* n_isect_dev, const float* backgrounds, const float* alphas,
                                     const int32_t* last_ids, const float* v_render, const float* v_alphas,
-                                    int absgrad, float* v_splats, void* stream) {
+                                    int absgrad, float* v_splats, long long n_gaussians, void* stream) {
     MI_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size must be 16");
     MI_REQUIRE(tile_width == mi_div_up(width, TILE) && tile_height == mi_div_up(height, TILE),
                "rasterize_bwd: tile grid does not match image size");
@@ -393,5 +395,6 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
     }
 #endif
     return mi_rasterize_bwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
-                                 n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, g_raster_mode, st);
+                                 n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, g_raster_mode,
+                                 n_gaussians, st);
 }

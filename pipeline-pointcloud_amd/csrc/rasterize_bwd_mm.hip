@@ -2,6 +2,7 @@
 // gfx950 only.  Replaces gsplat rasterize_to_pixels_bwd, reached by the reference only through
 // main.py:1312 / main.py:1343.  Built with -fno-slp-vectorize (see the Makefile).
 #include "rasterize_mfma.h"
+#include <stdlib.h>
 
 namespace mfma_raster {
 
@@ -32,42 +33,36 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int TR_STRIDE = 68;
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
-// ---- shape of the kernel (compile-time; the Makefile's BWD_SHAPE overrides them for same-box A/B builds, tools/raster_ab.py).
-//   MI_BWD_STG        splats per staged batch: 256 (one per thread) or 128 (LDS 50 -> 40 KB: room for four blocks per CU)
-//   MI_BWD_PIPELINE   1: a chunk's contraction is issued one MFMA per visit among the NEXT chunk's visits (16 + 4 more live
-//                     registers); 0: operands are read and the four MFMAs issued when the chunk ends
-//   MI_BWD_COL_AHEAD  the wave-uniform colour read runs this many visits ahead (3 registers each)
-//   MI_BWD_WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128)
-// Round 3 measured (profiles/r03_raster_bwd_occupancy_ab.txt): 128-slot batches with the pipelined contraction held to 128
-// VGPRs spill 39 registers and LOSE 8 % (S2) / 15 % (S1); without the pipelining and with the colour one visit ahead the
-// kernel needs 126 registers, no spills, four waves per SIMD.
-#ifndef MI_BWD_STG
-#define MI_BWD_STG 256
-#endif
-#ifndef MI_BWD_PIPELINE
-#define MI_BWD_PIPELINE 1
-#endif
-#ifndef MI_BWD_COL_AHEAD
-#define MI_BWD_COL_AHEAD 2
-#endif
-#ifndef MI_BWD_WAVES
-#define MI_BWD_WAVES 3
-#endif
-constexpr int STG = MI_BWD_STG;
-static_assert(STG == 128 || STG == 256, "MI_BWD_STG");
+// ---- two shapes of the kernel, chosen per launch by the number of Gaussians (mi_rasterize_bwd_mm):
+//   STG        splats per staged batch: 256 (one per thread) or 128 (LDS 50 -> 40 KB: room for four blocks per CU)
+//   PIPELINE   true: a chunk's contraction is issued one MFMA per visit among the NEXT chunk's visits (16 + 4 more live
+//              registers); false: operands are read and the four MFMAs issued when the chunk ends
+//   COL_AHEAD  the wave-uniform colour read runs this many visits ahead (3 registers each)
+//   WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 126)
+// DEEP = the round-2 kernel: fastest per wave, three waves per SIMD.  WIDE: 126 registers, 40 KB, four waves per SIMD.
+// Same-box A/B (profiles/r03_raster_bwd_shape_ab.txt, tools/raster_ab.py): S2 (2 M Gaussians, every tile a few hundred
+// reached splats) 459 -> 398 us with WIDE; S1 148 -> 144; the reference's wolf.spz at 960 x 720 (100 k Gaussians, the time is the
+// serial walk of a few hundred heavy tiles) 201 -> 205, with absgrad 271 -> 288: there a wave's own speed counts, not how many
+// waves wait beside it.  WIDE by the compiler's spiller instead (pipelining kept, 39 registers in scratch) LOST 8 - 15 %
+// (r03_raster_bwd_occupancy_ab.txt); WIDE's ingredients at three waves (no pipelining, 256-slot batches) lose 3 - 5 %.
+struct ShapeDeep { static constexpr int STG = 256, COL_AHEAD = 2, WAVES = 3; static constexpr bool PIPELINE = true; };
+struct ShapeWide { static constexpr int STG = 128, COL_AHEAD = 1, WAVES = 4; static constexpr bool PIPELINE = false; };
 // columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums (9..11; the flush adds
-// them), then |x|, |y|.  ABS_MERGE (ABSGRAD at four waves per SIMD, where the LDS has to stay under 40 KB): the lo colour sums
-// are added to the hi ones before they are stored (three lanes of the accumulator, one DPP shift each) and |x|, |y| take
+// them), then |x|, |y|.  MERGE (ABSGRAD at four waves per SIMD, where the LDS has to stay under 40 KB): the lo colour sums
+// are added to the hi ones before they are stored (three lanes of the accumulator, one cross-lane read each) and |x|, |y| take
 // columns 9, 10: eleven columns instead of fourteen.
-constexpr bool ABS_MERGE = MI_BWD_WAVES >= 4;
-constexpr int AW_ABSX = ABS_MERGE ? 9 : 12, AW_ABSY = ABS_MERGE ? 10 : 13;
+template <typename SH> struct AbsCols {
+    static constexpr bool MERGE = SH::WAVES >= 4;
+    static constexpr int ABSX = MERGE ? 9 : 12, ABSY = MERGE ? 10 : 13;
+};
 
 // LDS float atomics are lane-serial on this part (tools/micro/lds_ops.hip: ds_add_f32 takes ~3 LDS cycles per ACTIVE lane,
 // 55 for the 18 lanes that would add a chunk's sums, against 3 for a plain ds_write_b32), so every wave keeps its own sums
 // (plain stores, each (wave, slot, column) written at most once per group) and the flush adds the four quadrants.
-template <bool ABSGRAD>
+template <bool ABSGRAD, typename SH>
 struct StagedBwdMM {
-    static constexpr int AW = ABSGRAD ? (ABS_MERGE ? 11 : 14) : 12;
+    static constexpr int STG = SH::STG;
+    static constexpr int AW = ABSGRAD ? (AbsCols<SH>::MERGE ? 11 : 14) : 12;
     StagedN<STG> f;
     float4 geo[STG];          // mx, my (relative to the tile centre), A, B
     float2 geo2[STG];         // C, 1 / o
@@ -130,20 +125,20 @@ __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
 // WF (variant, MI3DGS_RASTER_MODE=14): the wave turns its own chunk's sums into gradient records and adds them to global
 // memory itself -- no per-wave sums kept for a block flush, no group barriers, but one 64-byte float-atomic request per
 // (quadrant, splat) instead of one per (tile, splat).
-template <bool ABSGRAD, bool WF, bool T3 = false>
-__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
+template <bool ABSGRAD, bool WF, bool T3, typename SH>
+__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane,
                                           float* __restrict__ v_splats) {
-    constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
+    constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
     constexpr int CH = (ABSGRAD || T3) ? 4 : 8;
     if (T3) {          // rows 8..15 (lanes 32..63) hold the sums of the third term: add them to rows 0..7
 #pragma unroll
         for (int r = 0; r < 4; r++) P.d[r] += __shfl_down(P.d[r], 32, 64);
     }
-    if (ABSGRAD && ABS_MERGE) {     // colour sums: column j + 3 (from the lo part of v_rgb) onto column j = 6..8 (row_shl:3 inside the 16-lane row)
+    if (ABSGRAD && AbsCols<SH>::MERGE) {     // colour sums: column j + 3 (from the lo part of v_rgb) onto column j = 6..8 (row_shl:3 inside the 16-lane row)
         const bool col = (lane & 15) >= 6 && (lane & 15) < 9;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P.d[r]), 0x103, 0xF, 0xF, true));
+            const float up = __shfl_down(P.d[r], 3, 64);          // lane j + 3 of the same 16-lane row (j <= 8)
             P.d[r] += col ? up : 0.f;
         }
     }
@@ -175,9 +170,9 @@ __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, co
                     case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + ac[AC_QUV]); break;
                     case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + ac[AC_QVV]); break;
                     case GR_OPA: val = M * g2.y; break;
-                    case GR_R: case GR_G: case GR_B: val = (ABSGRAD && ABS_MERGE) ? ac[comp] : ac[comp] + ac[comp + 3]; break;
-                    case GR_ABSX: val = ac[AW_ABSX < AW ? AW_ABSX : 0]; break;
-                    default: val = ac[AW_ABSY < AW ? AW_ABSY : 0]; break;
+                    case GR_R: case GR_G: case GR_B: val = (ABSGRAD && AbsCols<SH>::MERGE) ? ac[comp] : ac[comp] + ac[comp + 3]; break;
+                    case GR_ABSX: val = ac[AbsCols<SH>::ABSX < AW ? AbsCols<SH>::ABSX : 0]; break;
+                    default: val = ac[AbsCols<SH>::ABSY < AW ? AbsCols<SH>::ABSY : 0]; break;
                 }
                 atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
             }
@@ -185,8 +180,8 @@ __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, co
     }
 }
 
-template <bool ABSGRAD>
-__device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int wv, int lane, int slot0) {
+template <bool ABSGRAD, typename SH>
+__device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, int wv, int lane, int slot0) {
     asm volatile("" ::: "memory");      // the rows were written by other lanes of this wave: LDS is in order per wave
     const u4v* ap = reinterpret_cast<const u4v*>(&L.tr[wv][lane & 15][4 * (lane >> 4)]);
     P.a[0] = ap[0]; P.a[1] = ap[4]; P.a[2] = ap[8]; P.a[3] = ap[12];
@@ -196,20 +191,20 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int 
     P.on = true;
 }
 
-template <bool ABSGRAD, bool WF, bool T3 = false>
-__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane,
+template <bool ABSGRAD, bool WF, bool T3, typename SH>
+__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane,
                                          float* __restrict__ v_splats) {
     if (!P.on) return;
 #pragma unroll
     for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
-    mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
+    mm_finish<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);
 }
 
 // One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
 // FAST: every pixel of the wave that composited anything is already in range (index <= its last contributor).
 // gbit0: bit of this sub-batch's first chunk in the group's mask.
-template <bool ABSGRAD, bool FAST, int EXP>
-__device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
+template <bool ABSGRAD, bool FAST, int EXP, typename SH>
+__device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
                                                  int bin_final, unsigned long long has, const PixelBasis& px, const MMLane& mm,
                                                  MMPend& P, unsigned long long& gmask, const float (&vrgb)[3], float tail,
                                                  float& T, float& bufdot, float* __restrict__ v_splats) {
@@ -219,7 +214,7 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
     // colours two visits ahead: LDS serves a wave in order, so a read queues behind the two stores of the visit before it
-    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, MI_BWD_COL_AHEAD == 2 ? 1 : 0);
+    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, SH::COL_AHEAD == 2 ? 1 : 0);
     unsigned* trw = &L.tr[wv][0][lane];
     // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
     // bookkeeping counts like vector work.  A dead visit is a compare and a branch: its rows keep whatever they held, the
@@ -232,10 +227,10 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
         const int ci = i % CH;
         const Rgb col = (EXP & 2) ? Rgb{0.3f, 0.4f, 0.5f} : col_next;
         if (!(EXP & 2)) {
-            if (MI_BWD_COL_AHEAD == 2) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
+            if (SH::COL_AHEAD == 2) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
             else col_next = lds_rgb(uni, i + 1);
         }
-        if (MI_BWD_PIPELINE && ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
+        if (SH::PIPELINE && ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
         // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
         unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
         if (!FAST) valid &= mask_ge_i(bin_final, be - k);
@@ -277,13 +272,13 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const 
             }
         }
         if (ci == CH - 1) {
-            if (MI_BWD_PIPELINE && P.on) mm_finish<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);
+            if (SH::PIPELINE && P.on) mm_finish<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);
             const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
             if (cl) {
-                mm_read(L, P, wv, lane, gs0 + i - (CH - 1));
+                mm_read<ABSGRAD, SH>(L, P, wv, lane, gs0 + i - (CH - 1));
                 P.slot_abs = k - (CH - 1);
                 P.live = cl;
-                if (!MI_BWD_PIPELINE) mm_drain<ABSGRAD, WF, T3>(L, P, mm, wv, lane, v_splats);      // read, four MFMAs, store: nothing stays live
+                if (!SH::PIPELINE) mm_drain<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);      // read, four MFMAs, store: nothing stays live
             }
         }
     }
@@ -303,14 +298,15 @@ namespace mfma_raster {
 #define RB_STAMP(i, v) do { } while (0)
 #endif
 
-template <bool HAS_BG, bool ABSGRAD, int EXP>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WAVES, MI_BWD_WAVES))) void rasterize_bwd_mm_kernel(
+template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
-    constexpr int AW = StagedBwdMM<ABSGRAD>::AW;
-    __shared__ StagedBwdMM<ABSGRAD> L;
+    constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
+    constexpr int STG = SH::STG;
+    __shared__ StagedBwdMM<ABSGRAD, SH> L;
     const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
     if (t < 0) return;
     const int cam = t / (tw * th);
@@ -412,7 +408,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WA
         // columns of the product: 0..5 moments (AC_QU .. AC_Q), 6..8 colour sums from the hi part of v_rgb, 9..11 from its lo part
         if (ABSGRAD) {
             // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3
-            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < (ABS_MERGE ? 9 : 12) ? j : -1) : (j == 5 ? (g == 2 ? AW_ABSX : AW_ABSY) : -1);
+            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < (AbsCols<SH>::MERGE ? 9 : 12) ? j : -1) : (j == 5 ? (g == 2 ? AbsCols<SH>::ABSX : AbsCols<SH>::ABSY) : -1);
         } else if ((EXP & 8) != 0) {
             // three terms: rows Q 0..3, W 4..7 (words hi | mid), Q 8..11, W 12..15 (words lo | 0); groups 2, 3 are added to 0, 1 in mm_finish
             mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : -1;
@@ -452,11 +448,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WA
                 float s[SUB];
                 eval_sub_batch(L.f, sb, lane, basis, s);
                 if (be - sb * SUB <= wmin)
-                    bwd_sub_batch_mm<ABSGRAD, true, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
+                    bwd_sub_batch_mm<ABSGRAD, true, EXP, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
                 else
-                    bwd_sub_batch_mm<ABSGRAD, false, EXP>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
+                    bwd_sub_batch_mm<ABSGRAD, false, EXP, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
             }
-            mm_drain<ABSGRAD, (EXP & 4) != 0, (EXP & 8) != 0 && !ABSGRAD>(L, P, mm, wv, lane, v_splats);
+            mm_drain<ABSGRAD, (EXP & 4) != 0, (EXP & 8) != 0 && !ABSGRAD, SH>(L, P, mm, wv, lane, v_splats);
             if (EXP & 5) continue;          // 1: timing experiment, no group barriers, no flush; 4: the waves have flushed themselves
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
@@ -487,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WA
                     const float M = __shfl(sum, rb + AC_Q, 64), Mu = __shfl(sum, rb + AC_QU, 64), Mv = __shfl(sum, rb + AC_QV, 64);
                     // second operand by output component: x, y none; conic A, B, C their second moments; r, g, b the lo sums
                     const int xsrc = comp == GR_CA ? AC_QUU : comp == GR_CB ? AC_QUV : comp == GR_CC ? AC_QVV
-                                     : (!(ABSGRAD && ABS_MERGE) && comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AW_ABSX : comp == GR_ABSY ? AW_ABSY : 0;
+                                     : (!(ABSGRAD && AbsCols<SH>::MERGE) && comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AbsCols<SH>::ABSX : comp == GR_ABSY ? AbsCols<SH>::ABSY : 0;
                     const float X = __shfl(sum, rb + xsrc, 64);
                     if (slot < bsz && touched && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
                         const float4 ge = L.geo[slot];
@@ -502,7 +498,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WA
                             case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + X); break;
                             case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + X); break;
                             case GR_OPA: val = M * g2.y; break;
-                            case GR_R: case GR_G: case GR_B: val = (ABSGRAD && ABS_MERGE) ? sum : sum + X; break;
+                            case GR_R: case GR_G: case GR_B: val = (ABSGRAD && AbsCols<SH>::MERGE) ? sum : sum + X; break;
                             default: val = X; break;          // |x|, |y|
                         }
                         atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
@@ -517,41 +513,58 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MI_BWD_WA
 
 }  // namespace mfma_raster
 
+// Which shape: WIDE (four waves per SIMD) where many tiles of similar weight keep every CU busy, DEEP (fastest single wave)
+// where a few heavy tiles decide.  The host knows neither list lengths nor reached fractions without a sync; it knows the number
+// of Gaussians in the call, and the regimes measured separate on it (2 M and 300 k: WIDE wins by 13 % and 3 %; 100 k real
+// splats: DEEP wins by 2 - 6 %).  MI3DGS_BWD_WIDE_MIN moves the switch-over (documented tuning knob, include/mi3dgs.h).
+static long long bwd_wide_min() {
+    static const long long v = [] { const char* e = getenv("MI3DGS_BWD_WIDE_MIN"); return e ? atoll(e) : 200000ll; }();
+    return v;
+}
+
 // experiment: 0 = the product kernel, the only one the product library holds.  Experiments build (libmi3dgs_exp.so):
-// 14 = the wave-flush variant (correct); 11..13 = timing experiments with WRONG results, kept for the measurements quoted in
-// DESIGN.md (bit 0 no group barriers / flush, bit 1 no colour reads; only without background and absgrad)
-int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
+// 4 = three-term transport of the pixel sums (correct), 14 = the wave-flush variant (correct); 11..13 = timing experiments with
+// WRONG results, kept for the measurements quoted in docs/FINDINGS_r01_r02.md (bit 0 no group barriers / flush, bit 1 no colour
+// reads; only without background and absgrad); 21 / 22 = force the DEEP / WIDE shape
+int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
                         const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st) {
     using namespace mfma_raster;
-#define LAUNCH_MM(BG, AG, E)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
+#define LAUNCH_MM(BG, AG, E, SH)                                                                                                 \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands())
+    bool wide = n_gauss >= bwd_wide_min();
 #ifdef MI3DGS_EXPERIMENTS
+    if (experiment == 21 || experiment == 22) { wide = experiment == 22; experiment = 0; }
     if (experiment == 4 && !absgrad) {           // three-term transport of the pixel sums (correct results, 24 significant bits)
-        if (backgrounds) LAUNCH_MM(true, false, 8); else LAUNCH_MM(false, false, 8);
+        if (backgrounds) LAUNCH_MM(true, false, 8, ShapeDeep); else LAUNCH_MM(false, false, 8, ShapeDeep);
         MI_LAUNCH_CHECK();
         return 0;
     }
     if (experiment == 14) {           // wave-flush variant (correct results)
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4); else LAUNCH_MM(true, false, 4); }
-        else { if (absgrad) LAUNCH_MM(false, true, 4); else LAUNCH_MM(false, false, 4); }
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4, ShapeDeep); else LAUNCH_MM(true, false, 4, ShapeDeep); }
+        else { if (absgrad) LAUNCH_MM(false, true, 4, ShapeDeep); else LAUNCH_MM(false, false, 4, ShapeDeep); }
         MI_LAUNCH_CHECK();
         return 0;
     }
     if (experiment >= 11 && experiment <= 13 && !backgrounds && !absgrad) {
-        if (experiment == 11) LAUNCH_MM(false, false, 1);
-        else if (experiment == 12) LAUNCH_MM(false, false, 2);
-        else LAUNCH_MM(false, false, 3);
+        if (experiment == 11) LAUNCH_MM(false, false, 1, ShapeDeep);
+        else if (experiment == 12) LAUNCH_MM(false, false, 2, ShapeDeep);
+        else LAUNCH_MM(false, false, 3, ShapeDeep);
         MI_LAUNCH_CHECK();
         return 0;
     }
 #endif
     MI_REQUIRE(experiment == 0, "rasterize_bwd: unknown variant");
-    if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0); else LAUNCH_MM(true, false, 0); }
-    else { if (absgrad) LAUNCH_MM(false, true, 0); else LAUNCH_MM(false, false, 0); }
+    if (wide) {
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0, ShapeWide); else LAUNCH_MM(true, false, 0, ShapeWide); }
+        else { if (absgrad) LAUNCH_MM(false, true, 0, ShapeWide); else LAUNCH_MM(false, false, 0, ShapeWide); }
+    } else {
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0, ShapeDeep); else LAUNCH_MM(true, false, 0, ShapeDeep); }
+        else { if (absgrad) LAUNCH_MM(false, true, 0, ShapeDeep); else LAUNCH_MM(false, false, 0, ShapeDeep); }
+    }
 #undef LAUNCH_MM
     MI_LAUNCH_CHECK();
     return 0;

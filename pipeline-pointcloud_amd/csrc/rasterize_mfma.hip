@@ -332,7 +332,7 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
     return 0;
 }
 
-int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
+int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
                         const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st);
@@ -340,7 +340,7 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int mode, hipStream_t st) {
+                          const float* v_alphas, int absgrad, float* v_splats, int mode, long long n_gauss, hipStream_t st) {
     using namespace mfma_raster;
     // mode 1: the contraction on the matrix pipe (rasterize_bwd_mm.hip), the product path and the only one of the product
     // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 and 11..14 = variants of the product
@@ -358,6 +358,6 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
         return 0;
     }
 #endif
-    return mi_rasterize_bwd_mm(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids, n_isect_dev,
+    return mi_rasterize_bwd_mm(n_tiles, width, height, tile_width, tile_height, n_gauss, splats, isect_offsets, flatten_ids, n_isect_dev,
                                backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, mode == 1 ? 0 : mode, st);
 }

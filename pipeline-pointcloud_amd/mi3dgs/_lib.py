@@ -56,7 +56,7 @@ _SIGNATURES = {
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_scan_exclusive_u32": (_i, [_f, _f, _ll, _f, _f, _sz, _f]),
     "mi3dgs_rasterize_fwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _f]),
+    "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _ll, _f]),
     "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_scale_reg": (_i, [_i, _f, _fl, _fl, _f, _f, _f]),

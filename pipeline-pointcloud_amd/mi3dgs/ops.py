@@ -241,7 +241,7 @@ def rasterize_bwd(splats, binning, width, height, alphas, last_ids, v_render, v_
     _lib.call("mi3dgs_rasterize_bwd", Cn, int(width), int(height), tile_size, binning["tile_width"],
               binning["tile_height"], _p(splats), _p(binning["isect_offsets"]), _p(binning["flatten_ids"]),
               _p(binning["n_isect"]), _p(backgrounds), _p(alphas), _p(last_ids), _p(v_render), _p(v_alphas),
-              int(bool(absgrad)), _p(v_splats), _stream(dev))
+              int(bool(absgrad)), _p(v_splats), int(N), _stream(dev))
     return v_splats
 
 

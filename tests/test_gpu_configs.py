@@ -223,9 +223,11 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         assert a_ref.mean() > 0.05
         # Two thousand splats deep, a handful of splats with near-equal depth sit at a DIFFERENT list position under float32
         # depth keys than under the oracle's float64 depths.  Where two such splats overlap on screen, each sees the other's alpha
-        # in its transmittance or not, and everything in FRONT of them (same pixels) sees another colour behind it: a first-order
-        # difference for exactly those Gaussians and no others.  They are identified from the two depth orders and the screen
-        # boxes (not picked by their error, as round 2's "eight worst" were) and set aside; everything else is held to 2e-3.
+        # in its transmittance or not: a first-order difference (relative alpha_j) in exactly those two Gaussians' gradients.
+        # (Splats in FRONT of the pair see another colour behind them, T_pair alpha_i alpha_j (c_i - c_j): second order and
+        # scaled by the transmittance left at the pair's depth; splats behind it see no difference at all.)  The pairs are
+        # identified from the two depth orders and the screen boxes -- not picked by their error, as round 2's "eight worst"
+        # were -- and set aside; everything else is held to 2e-3.
         sp32 = meta["splats"][0].cpu()[idx]
         d32 = sp32[:, 9].contiguous().view(torch.int32).long()            # float32 depth > 0: the bit pattern orders like the value
         d64 = proj64[2][0][idx]
@@ -240,17 +242,13 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         lo, hi = sp32[:, 0:2].double() - rad, sp32[:, 0:2].double() + rad
         n_pairs = 0
         for m in moved.tolist():
-            # the splats whose order relative to m differs between the two sorts (normally one neighbour), where their screen
-            # boxes overlap: there m and its partner see each other's alpha or not, and every splat in front that reaches into
-            # that overlap sees another colour behind it
+            # the splats whose order relative to m differs between the two sorts (normally one neighbour), where their screen boxes overlap
             part = moved[(torch.sign(pos32[moved] - pos32[m]) != torch.sign(pos64[moved] - pos64[m]))]
             for j in part.tolist():
                 rlo, rhi = torch.maximum(lo[m], lo[j]), torch.minimum(hi[m], hi[j])
                 if bool((rlo < rhi).all()):
                     n_pairs += 1
                     aside[m] = aside[j] = True
-                    ov = (lo[:, 0] < rhi[0]) & (hi[:, 0] > rlo[0]) & (lo[:, 1] < rhi[1]) & (hi[:, 1] > rlo[1])
-                    aside |= ov & (pos64 < min(int(pos64[m]), int(pos64[j])))
         keep = ~aside
         assert int(keep.sum()) > 0.8 * idx.numel(), (kind, (x0, y0), "exclusion swallowed the crop", int(aside.sum()), idx.numel(), n_pairs)
         for k in ("means", "quats", "scales", "opacities", "sh"):
@@ -326,7 +324,7 @@ def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad
     try:
         ops._lib.exp_call("mi3dgs_rasterize_bwd", 1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
                           ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(a), ops._p(l), ops._p(vr), ops._p(va),
-                          int(absgrad), ops._p(rs_out), ops._stream(dev))
+                          int(absgrad), ops._p(rs_out), int(splats.shape[1]), ops._stream(dev))
         torch.cuda.synchronize()
     finally:
         ex.mi3dgs_debug_set_raster_mode(1)

@@ -57,16 +57,18 @@ def main():
         for name in ("mi3dgs_rasterize_bwd", "mi3dgs_rasterize_fwd", "mi3dgs_debug_set_raster_mode", "mi3dgs_last_error"):
             fn = getattr(h, name)
             fn.restype, fn.argtypes = _lib._SIGNATURES[name]
+        h.mi3dgs_abi_version.restype = C.c_int
+        h._abi = h.mi3dgs_abi_version()
+        if h._abi < 4:           # round-2 builds: no n_gaussians argument
+            h.mi3dgs_rasterize_bwd.argtypes = _lib._SIGNATURES["mi3dgs_rasterize_bwd"][1][:-2] + [C.c_void_p]
         if a.modes:
             assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
         handles.append(h)
 
-    def bwd(h, out):
-        out.zero_()
-        rc = h.mi3dgs_rasterize_bwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
-                                    ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last), ops._p(vr),
-                                    ops._p(va), int(a.absgrad), ops._p(out), st)
-        assert rc == 0, h.mi3dgs_last_error()
+    def bwd_args(h, out):
+        head = (1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]), ops._p(b["flatten_ids"]),
+                ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last), ops._p(vr), ops._p(va), int(a.absgrad), ops._p(out))
+        return head + ((N, st) if h._abi >= 4 else (st,))
 
     def fwd(h, o):
         rc = h.mi3dgs_rasterize_fwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
@@ -87,9 +89,7 @@ def main():
                     assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
                 e0.record()
                 if fn is bwd:
-                    rc = h.mi3dgs_rasterize_bwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
-                                                ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last),
-                                                ops._p(vr), ops._p(va), int(a.absgrad), ops._p(arg), st)
+                    rc = h.mi3dgs_rasterize_bwd(*bwd_args(h, arg))
                     assert rc == 0, h.mi3dgs_last_error()
                 else:
                     fwd(h, arg)
