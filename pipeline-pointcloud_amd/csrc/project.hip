@@ -258,17 +258,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // per-lane gather that everything else would have to wait for
     Cam cam = (C == 1) ? load_cam(viewmats, Ks, 0) : load_cam(viewmats, Ks, c);
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
-    // the opacity travels with the means (it used to be a separate round trip after the projection)
+    // the opacity travels with the means (it used to be a separate round trip after the projection) -- and, since round 3, so do
+    // the quaternion, the scales and the DC colour: they used to be requested behind the depth test (`if (ok)`), one more
+    // dependent memory round trip per wave for the sake of 40 bytes of the culled third of the Gaussians (+27 MB of 441)
     const float opa_raw = opacities != nullptr ? opacities[n] : 1.f;
+    const float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (long long)n);
+    const float s_raw[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    float c0[3] = {0.f, 0.f, 0.f};
+    if (color_mode == 0) { c0[0] = sh0[3 * (long long)n]; c0[1] = sh0[3 * (long long)n + 1]; c0[2] = sh0[3 * (long long)n + 2]; }
+    asm volatile("" :: "v"(q4.x), "v"(s_raw[0]), "v"(c0[0]));          // (keeps these loads in front of the branch below: hipcc sinks them into it)
     float zc = cam.R[6] * mean[0] + cam.R[7] * mean[1] + cam.R[8] * mean[2] + cam.t[2];
     bool ok = live && (zc >= near_plane) && (zc <= far_plane);
     Proj P;
     float opa = 1.f;
     float rx = 0.f, ry = 0.f;
     if (ok) {
-        float4 q4 = *reinterpret_cast<const float4*>(quats + 4 * (long long)n);
         float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+        float s[3] = {s_raw[0], s_raw[1], s_raw[2]};
         if (flags & MI_FLAG_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
         float Rq[9], inv_norm, Sw[9];
         quat_to_rotmat(q, Rq, inv_norm);
@@ -295,8 +301,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     // ---- stage this wave's shN slice (wave-uniform decision); the DC coefficients are requested in the
     // same breath (they used to be one more round trip after the slice)
-    float c0[3] = {0.f, 0.f, 0.f};
-    if (color_mode == 0 && ok) { c0[0] = sh0[3 * (long long)n]; c0[1] = sh0[3 * (long long)n + 1]; c0[2] = sh0[3 * (long long)n + 2]; }
     bool staged = false;
     float staged_rgb[3] = {0.f, 0.f, 0.f};          // the shN part of the colour when the slice went through LDS
     float b[16];                                    // SH basis of the view direction (zeros for a culled lane)

@@ -35,18 +35,27 @@ def _ops():
     return ops
 
 
-def _oracle_fwd_bwd(A, viewmats, Ks, W, H, wr, wa, sh_degree=3, bg=None):
+def _oracle_fwd_bwd(A, viewmats, Ks, W, H, wr, wa, sh_degree=3, bg=None, sort_depths=None):
     """float64 oracle, one camera at a time (bounds the autograd graph); returns renders, alphas and the
-    gradients of sum(render * wr) + sum(alpha * wa) for the five parameter groups."""
+    gradients of sum(render * wr) + sum(alpha * wa) for the five parameter groups.
+    sort_depths [C, N] (optional): the float32 depths to build the tile-list sort keys from, instead of the oracle's own float64
+    depths rounded to float32 -- the list ORDER is a discrete decision taken on float32 depth bits (gsplat's keys and this
+    library's alike), and two depths one ulp apart in float32 arithmetic can round the other way from float64."""
     leaves = {k: v.clone().double().requires_grad_(True) for k, v in A.items()}
     rs, als = [], []
-    for c in range(viewmats.shape[0]):
-        r, a, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["sh"],
-                                  viewmats[c:c + 1].double(), Ks[c:c + 1].double(), W, H, sh_degree=sh_degree,
-                                  backgrounds=None if bg is None else bg[c:c + 1].double())
-        ((r * wr[c:c + 1]).sum() + (a * wa[c:c + 1]).sum()).backward()
-        rs.append(r.detach())
-        als.append(a.detach())
+    orig = O.isect_tiles
+    try:
+        for c in range(viewmats.shape[0]):
+            if sort_depths is not None:
+                O.isect_tiles = (lambda m2d, rad, dep, *a, _c=c, **k: orig(m2d, rad, sort_depths[_c:_c + 1].to(dep), *a, **k))
+            r, a, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["sh"],
+                                      viewmats[c:c + 1].double(), Ks[c:c + 1].double(), W, H, sh_degree=sh_degree,
+                                      backgrounds=None if bg is None else bg[c:c + 1].double())
+            ((r * wr[c:c + 1]).sum() + (a * wa[c:c + 1]).sum()).backward()
+            rs.append(r.detach())
+            als.append(a.detach())
+    finally:
+        O.isect_tiles = orig
     return torch.cat(rs), torch.cat(als), {k: v.grad for k, v in leaves.items()}
 
 
@@ -217,44 +226,22 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         wr = torch.randn(1, ch, cw, 3, generator=g, dtype=torch.float64)
         wa = torch.randn(1, ch, cw, 1, generator=g, dtype=torch.float64)
         bg = torch.rand(1, 3, generator=g, dtype=torch.float64)
-        r_ref, a_ref, g_ref = _oracle_fwd_bwd({k: v[idx] for k, v in A.items()}, vm, Kc, cw, ch, wr, wa, bg=bg)
         r, a, gr, meta = _hip_fwd_bwd(A, vm, Kc, cw, ch, wr, wa, dev, bg=bg)
+        # The oracle builds its tile lists from the SAME float32 depth values the library sorted by (the splat records' depth
+        # slot): two thousand splats deep, a few hundred pairs of depths differ by an ulp between float32 arithmetic and
+        # float64-then-rounded, and where such a pair overlaps on screen the two orders give each splat another transmittance --
+        # a discrete decision, not an arithmetic error.  Round 2 set "the eight worst Gaussians" aside for it; with the order
+        # shared nothing is set aside and every Gaussian is held to 2e-3.
+        sp32 = meta["splats"][0].cpu()[idx]
+        d64 = proj64[2][0][idx]
+        moved = int((torch.argsort(torch.argsort(sp32[:, 9].double(), stable=True)) != torch.argsort(torch.argsort(d64, stable=True))).sum())
+        r_ref, a_ref, g_ref = _oracle_fwd_bwd({k: v[idx] for k, v in A.items()}, vm, Kc, cw, ch, wr, wa, bg=bg,
+                                              sort_depths=sp32[None, :, 9].double())
         _check_images(r, a, r_ref, a_ref, mean_tol=1e-4, q_tol=5e-3, max_tol=5e-2)
         assert a_ref.mean() > 0.05
-        # Two thousand splats deep, a handful of splats with near-equal depth sit at a DIFFERENT list position under float32
-        # depth keys than under the oracle's float64 depths.  Where two such splats overlap on screen, each sees the other's alpha
-        # in its transmittance or not: a first-order difference (relative alpha_j) in exactly those two Gaussians' gradients.
-        # (Splats in FRONT of the pair see another colour behind them, T_pair alpha_i alpha_j (c_i - c_j): second order and
-        # scaled by the transmittance left at the pair's depth; splats behind it see no difference at all.)  The pairs are
-        # identified from the two depth orders and the screen boxes -- not picked by their error, as round 2's "eight worst"
-        # were -- and set aside; everything else is held to 2e-3.
-        sp32 = meta["splats"][0].cpu()[idx]
-        d32 = sp32[:, 9].contiguous().view(torch.int32).long()            # float32 depth > 0: the bit pattern orders like the value
-        d64 = proj64[2][0][idx]
-        pos32 = torch.empty_like(idx)
-        pos32[torch.argsort(d32 * (idx.max() + 1) + idx)] = torch.arange(idx.numel())      # (depth key, Gaussian index): the library's order
-        pos64 = torch.empty_like(idx)
-        pos64[torch.argsort(d64, stable=True)] = torch.arange(idx.numel())
-        moved = torch.nonzero(pos32 != pos64).flatten()
-        assert moved.numel() <= max(16, idx.numel() // 50), (kind, (x0, y0), "too many order differences", int(moved.numel()))
-        aside = torch.zeros(idx.numel(), dtype=torch.bool)
-        rad = meta["radii"][0].cpu()[idx].double()
-        lo, hi = sp32[:, 0:2].double() - rad, sp32[:, 0:2].double() + rad
-        n_pairs = 0
-        for m in moved.tolist():
-            # the splats whose order relative to m differs between the two sorts (normally one neighbour), where their screen boxes overlap
-            part = moved[(torch.sign(pos32[moved] - pos32[m]) != torch.sign(pos64[moved] - pos64[m]))]
-            for j in part.tolist():
-                rlo, rhi = torch.maximum(lo[m], lo[j]), torch.minimum(hi[m], hi[j])
-                if bool((rlo < rhi).all()):
-                    n_pairs += 1
-                    aside[m] = aside[j] = True
-        keep = ~aside
-        assert int(keep.sum()) > 0.8 * idx.numel(), (kind, (x0, y0), "exclusion swallowed the crop", int(aside.sum()), idx.numel(), n_pairs)
         for k in ("means", "quats", "scales", "opacities", "sh"):
-            d = (gr[k][idx].double() - g_ref[k]).reshape(idx.numel(), -1)
-            e_all, e_rest = rel_err(gr[k][idx], g_ref[k]), float(d[keep].norm() / g_ref[k].reshape(idx.numel(), -1)[keep].norm())
-            assert e_all < 1e-2 and e_rest < 2e-3, (kind, (x0, y0), k, e_all, e_rest, int(moved.numel()), n_pairs, int(aside.sum()))
+            e_all = rel_err(gr[k][idx], g_ref[k])
+            assert e_all < 2e-3, (kind, (x0, y0), k, e_all, "list positions that differ between float32 and float64 depths:", moved)
             rest = gr[k].clone()
             rest[idx] = 0
             assert float(rest.norm()) <= 1e-3 * float(gr[k].norm()), (k, "gradient outside the oracle's visible set")

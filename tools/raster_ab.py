@@ -82,13 +82,13 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(a.reps + 2):
         for i, h in enumerate(handles):
-            for fn, arg, acc in ((bwd, outs[i], tb[i]), (fwd, fo[i], tf[i])):
-                if fn is bwd:
+            for fn, arg, acc in (("bwd", outs[i], tb[i]), (fwd, fo[i], tf[i])):
+                if fn == "bwd":
                     arg.zero_()
                 if a.modes:      # (the same library loaded twice is ONE handle with one mode word: set it for every launch)
                     assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
                 e0.record()
-                if fn is bwd:
+                if fn == "bwd":
                     rc = h.mi3dgs_rasterize_bwd(*bwd_args(h, arg))
                     assert rc == 0, h.mi3dgs_last_error()
                 else:
