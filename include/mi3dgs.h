@@ -58,7 +58,7 @@ extern "C" {
  * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
  * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);
-int mi3dgs_abi_version(void);      /* 4 */
+int mi3dgs_abi_version(void);      /* 5 */
 int mi3dgs_splat_stride(void);
 int mi3dgs_grad_stride(void);
 
@@ -190,7 +190,16 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
                          int tile_height, const float* splats, const int32_t* isect_offsets,
                          const int32_t* flatten_ids, const int32_t* n_isect_dev,
                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids,
+                         void* seg_workspace /* nullable */, size_t seg_workspace_bytes,
                          void* stream);
+/* Segment workspace (optional, training only).  One block walks a tile's list serially in the backward, so a launch is as
+ * long as its heaviest tile.  Given this workspace the forward leaves its per-pixel state (T, r, g, b) at every 512-entry
+ * boundary a tile's block walks past, and the backward -- given the SAME workspace and the forward's `render` -- processes the
+ * 512 entries in front of each boundary as work items of their own (1024 extra blocks looping over the list) while the tile's
+ * block keeps the rest.  Same gradients up to f32 rounding of (final colour - checkpoint colour).  Nothing is left for tiles
+ * that stop before 512 entries.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per
+ * possible boundary (max_isect / 512 of them), touched only where boundaries exist. */
+size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect);
 /* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it.
  * Numerics: log2 alpha of a (pixel, splat) pair is evaluated by the forward's own instruction sequence (three-term bf16
  * coefficients against an exact bf16 basis, f32 accumulation), so forward and backward take the same alpha >= 1/255 decision;
@@ -203,7 +212,9 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
                          const float* backgrounds, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, int absgrad, float* v_splats,
                          long long n_gaussians /* rows of `splats` per camera: picks the kernel shape (0 = unknown) */,
-                         void* stream);
+                         const float* render /* the forward's output; needed with seg_workspace only */,
+                         void* seg_workspace /* nullable: the one the forward of this step was given */,
+                         size_t seg_workspace_bytes, void* stream);
 
 /* Product library: accepts 1 (the MFMA rasterisers, the only ones it holds) and fails for anything else.  Experiments
  * library: 0 = round-1 all-VALU kernels, 3 = f32 reduce-scatter backward, 4 = three-term bf16 backward, 14 = wave-flush

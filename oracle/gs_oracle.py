@@ -214,8 +214,14 @@ def isect_offset_encode(isect_ids: torch.Tensor, C: int, tile_width: int, tile_h
 # -------------------------------------------------------------------------- compositing
 def rasterize_to_pixels(means2d, conics, colors, opacities, width: int, height: int,
                         tile_size: int, isect_offsets, flatten_ids,
-                        backgrounds: Optional[torch.Tensor] = None):
+                        backgrounds: Optional[torch.Tensor] = None, marginal: Optional[dict] = None):
     """gsplat `rasterize_to_pixels`: front-to-back alpha compositing per tile.
+
+    marginal (checker-side diagnostic, not part of gsplat): a dict that receives "alpha_skip" = bool [C,H,W], true where the
+    `alpha < 1/255 -> skip` decision of some splat the pixel reaches is closer to its threshold than float32 can resolve:
+    |sigma - ln(255 o)| <= ulps * 2^-24 * (|A| dx^2 / 2 + |C| dy^2 / 2 + |B dx dy|) + 1e-6, ulps = marginal["ulps"] (default 16).
+    A float32 implementation (gsplat's kernels, this repository's) may take that decision either way; each flip moves the
+    pixel's colour by one splat's alpha >= 1/255, so parity tests weigh such pixels with zero instead of excusing Gaussians.
 
     means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] -> render[C,H,W,D],
     alphas[C,H,W,1], last_ids[C,H,W] (index into flatten_ids of the last splat composited,
@@ -237,6 +243,7 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width: int, height: 
     alphas = torch.zeros(C, height, width, 1, dtype=dt)
     last_ids = torch.zeros(C, height, width, dtype=torch.int32)
     rows, cols = [], []
+    marg_rows = []
     for c in range(C):
         for ty in range(TH):
             for tx in range(TW):
@@ -263,6 +270,13 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width: int, height: 
                     T_incl = torch.cumprod(one_m, dim=1)
                     T_excl = torch.cat([torch.ones(P, 1, dtype=dt), T_incl[:, :-1]], dim=1)
                     live = (T_incl > TRANSMITTANCE_STOP).detach()        # prefix-closed
+                    if marginal is not None:
+                        with torch.no_grad():
+                            terms = 0.5 * (cn[:, 0].abs() * dx * dx + cn[:, 2].abs() * dy * dy) + (cn[:, 1] * dx * dy).abs()
+                            s_th = torch.log(o_f[ids] / ALPHA_THRESHOLD)[None, :]
+                            near = (sigma - s_th).abs() <= float(marginal.get("ulps", 16)) * 2.0 ** -24 * terms + 1e-6
+                            reached = torch.cat([torch.ones(P, 1, dtype=torch.bool), live[:, :-1]], dim=1)
+                            marg_rows.append((c, py.flatten(), px.flatten(), (near & reached).any(dim=1)))
                     w = alpha * T_excl * live
                     rgb = w @ col_f[ids]
                     T_fin = torch.prod(torch.where(live, one_m, torch.ones_like(one_m)), dim=1)
@@ -283,6 +297,11 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, width: int, height: 
         alphas = alphas.reshape(-1).index_put((pix,), torch.cat([r[4] for r in rows])).reshape(C, height, width, 1)
         last_ids = last_ids.reshape(-1).index_put((pix,), torch.cat([r[5] for r in rows]).to(torch.int32)).reshape(
             C, height, width)
+    if marginal is not None:
+        m = torch.zeros(C * height * width, dtype=torch.bool)
+        if marg_rows:
+            m[torch.cat([(c * height + py) * width + px for c, py, px, _ in marg_rows])] = torch.cat([r[3] for r in marg_rows])
+        marginal["alpha_skip"] = m.reshape(C, height, width)
     return render, alphas, last_ids
 
 
@@ -290,7 +309,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width: 
                   near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
                   eps2d: float = EPS2D, sh_degree: Optional[int] = None, tile_size: int = 16,
                   backgrounds: Optional[torch.Tensor] = None, rasterize_mode: str = "classic",
-                  absgrad: bool = False) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
+                  absgrad: bool = False, marginal: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """gsplat `rasterization(...)` (SURVEY.md 8b tier 2), unpacked path.
 
     scales are already exp()'d and opacities already sigmoid()'d, as the callers pass them.
@@ -322,7 +341,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width: 
         means2d.retain_grad() if means2d.requires_grad else None
     render, alphas, last_ids = rasterize_to_pixels(
         means2d, conics, cols, op, width, height, tile_size, isect_offsets, flatten_ids,
-        backgrounds=backgrounds)
+        backgrounds=backgrounds, marginal=marginal)
     meta = dict(radii=radii, means2d=means2d, depths=depths, conics=conics, opacities=op,
                 colors=cols, tiles_per_gauss=tiles_per_gauss, isect_ids=isect_ids,
                 flatten_ids=flatten_ids, isect_offsets=isect_offsets, last_ids=last_ids,

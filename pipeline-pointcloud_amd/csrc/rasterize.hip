@@ -319,11 +319,13 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
-                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st);
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, void* seg_ws, size_t seg_ws_bytes,
+                          hipStream_t st);
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int variant, long long n_gauss, hipStream_t st);
+                          const float* v_alphas, int absgrad, float* v_splats, int variant, long long n_gauss, const float* render,
+                          void* seg_ws, size_t seg_ws_bytes, hipStream_t st);
 static int g_raster_mode = 1;
 // Mode 1 = the product kernels, the only mode the product library has.  The experiments build (libmi3dgs_exp.so) adds:
 // 0 = round-1 VALU kernels; 3 = MFMA forward + backward with the all-f32 cross-lane reduce-scatter instead of the bf16 MFMA
@@ -346,7 +348,7 @@ extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
 extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
                                     const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                                     const int32_t* n_isect_dev, const float* backgrounds, float* render,
-                                    float* alphas, int32_t* last_ids, void* stream) {
+                                    float* alphas, int32_t* last_ids, void* seg_ws, size_t seg_ws_bytes, void* stream) {
     MI_REQUIRE(tile_size == TILE, "rasterize_fwd: tile_size must be 16");
     MI_REQUIRE(C > 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
     MI_REQUIRE(tile_width == mi_div_up(width, TILE) && tile_height == mi_div_up(height, TILE),
@@ -368,14 +370,15 @@ extern "C" int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size,
     }
 #endif
     return mi_rasterize_fwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
-                                 n_isect_dev, backgrounds, render, alphas, last_ids, st);
+                                 n_isect_dev, backgrounds, render, alphas, last_ids, seg_ws, seg_ws_bytes, st);
 }
 
 extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_width, int tile_height,
                                     const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                                     const int32_t* n_isect_dev, const float* backgrounds, const float* alphas,
                                     const int32_t* last_ids, const float* v_render, const float* v_alphas,
-                                    int absgrad, float* v_splats, long long n_gaussians, void* stream) {
+                                    int absgrad, float* v_splats, long long n_gaussians, const float* render, void* seg_ws,
+                                    size_t seg_ws_bytes, void* stream) {
     MI_REQUIRE(tile_size == TILE, "rasterize_bwd: tile_size must be 16");
     MI_REQUIRE(tile_width == mi_div_up(width, TILE) && tile_height == mi_div_up(height, TILE),
                "rasterize_bwd: tile grid does not match image size");
@@ -396,5 +399,5 @@ extern "C" int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size,
 #endif
     return mi_rasterize_bwd_mfma(n_tiles, width, height, tile_width, tile_height, splats, isect_offsets, flatten_ids,
                                  n_isect_dev, backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, g_raster_mode,
-                                 n_gaussians, st);
+                                 n_gaussians, render, seg_ws, seg_ws_bytes, st);
 }

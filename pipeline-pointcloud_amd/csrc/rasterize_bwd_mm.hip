@@ -298,21 +298,32 @@ namespace mfma_raster {
 #define RB_STAMP(i, v) do { } while (0)
 #endif
 
+// One walk of rasterize_bwd: the entries [lo, ...] of tile t's list, back to front, for the block's 256 pixels.
+//   item < 0: the tile's own block -- everything behind the last boundary the forward left (the whole list if it left none);
+//   item >= 0: segment `item` of the work list -- the SEG entries in front of a boundary, state from the forward's checkpoint.
 template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
+__device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int item, const SegWs& seg, const float* __restrict__ render,
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
     constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
     constexpr int STG = SH::STG;
-    __shared__ StagedBwdMM<ABSGRAD, SH> L;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
-    if (t < 0) return;
+    const bool worker = item >= 0;
+    int seg_lo = 0;
+    uint32_t slot_ck = 0;
+    if (worker) {
+        const uint4 wk = seg.work[item];
+        t = (int)wk.x; seg_lo = (int)wk.y; slot_ck = wk.z;
+    }
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    int lane = lane_id(), wv = threadIdx.x >> 6;  
+    // a segment worker runs this walk in a loop: what depends on the thread alone must be recomputed per walk, not kept in
+    // registers across it (hoisted, those values cost 33 - 38 spilled VGPRs)
+    asm volatile("" : "+v"(lane), "+v"(wv));
+    const int tid = wv * 64 + lane;
     int lx, ly;
     pixel_of_lane(wv, lane, lx, ly);
     const int px_i = tx * TILE + lx, py_i = ty * TILE + ly;
@@ -321,8 +332,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
     PixelBasis px;
     px.u = (float)lx - 7.5f; px.v = (float)ly - 7.5f;
     px.uu = px.u * px.u; px.uv = px.u * px.v; px.vv = px.v * px.v;
-    const int start = tile_offsets[t];
-    const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+    int start, end;
+    if (worker) {
+        start = seg_lo; end = seg_lo + SEG;
+    } else {
+        start = tile_offsets[t];
+        end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+        if (seg.ckpt) start += (int)seg.tile_nb[t] * SEG;
+    }
     RB_STAMP(0, wall_clock64()); RB_STAMP(1, 0ull); RB_STAMP(2, 0ull);
     // the pixel's values do not depend on the tile's range: requested before the range is looked at, so that they travel
     // beside the two offsets instead of behind them (a block's life starts with four dependent round trips otherwise:
@@ -342,9 +359,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
     if (end <= start) return;
     const float vrgb[3] = {vr0, vr1, vr2};
     float tail = T_final * va;                      // T_final (v_alpha - bg . v_rgb)
+    float bgdot = 0.f;
     if (HAS_BG) {
         const float* bg = backgrounds + 3 * cam;
-        tail -= T_final * (bg[0] * vr0 + bg[1] * vr1 + bg[2] * vr2);
+        bgdot = bg[0] * vr0 + bg[1] * vr1 + bg[2] * vr2;
+        tail -= T_final * bgdot;
+    }
+    float T = T_final;
+    float bufdot = 0.f;                         // (colour accumulated behind the current splat) . v_rgb
+    if (bin_final < start) bin_final = -1;      // its contributors all lie in front of this walk's range
+    if (worker && bin_final >= end) {
+        // the pixel went on past the boundary: enter the segment with the forward's own state there
+        const size_t pix = ((size_t)cam * H + py_i) * W + px_i;
+        const float4 ck = seg.ckpt[(size_t)slot_ck * BLOCK + tid];
+        const float r0 = render[3 * pix], r1 = render[3 * pix + 1], r2 = render[3 * pix + 2];
+        T = ck.x;
+        // colour composited behind the boundary = final colour - background share - colour at the boundary
+        bufdot = (r0 - ck.y) * vr0 + (r1 - ck.z) * vr1 + (r2 - ck.w) * vr2 - T_final * bgdot;
+        bin_final = end - 1;
     }
     int wmax = bin_final;
 #pragma unroll
@@ -419,22 +451,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
         }
     }
 
-    float T = T_final;
-    float bufdot = 0.f;                         // (colour accumulated behind the current splat) . v_rgb
     const unsigned long long has = wave_ballot(bin_final >= 0);
     MMPend P;
     P.on = false;
     for (int be = bmax; be >= start; be -= STG) {
         __syncthreads();
-        if (threadIdx.x < STG) {
-            const int j1 = be - (int)threadIdx.x;
+        if (tid < STG) {
+            const int j1 = be - tid;
             const int id_cur = j1 >= start ? flatten_ids[j1] : -1;
             const RecRegs rec = load_rec(splats, id_cur);
-            stage_splat(L.f, (int)threadIdx.x, rec, xc, yc);
+            stage_splat(L.f, tid, rec, xc, yc);
             if (id_cur >= 0) {
-                L.geo[threadIdx.x] = make_float4(rec.a.x - xc, rec.a.y - yc, rec.a.z, rec.a.w);
-                L.geo2[threadIdx.x] = make_float2(rec.bb.x, rec.bb.y > 0.f ? 1.f / rec.bb.y : 0.f);
-                L.id[threadIdx.x] = id_cur;
+                L.geo[tid] = make_float4(rec.a.x - xc, rec.a.y - yc, rec.a.z, rec.a.w);
+                L.geo2[tid] = make_float2(rec.bb.x, rec.bb.y > 0.f ? 1.f / rec.bb.y : 0.f);
+                L.id[tid] = id_cur;
             }
         }
         __syncthreads();
@@ -511,6 +541,39 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
     RB_STAMP(1, wall_clock64());
 }
 
+// The first `n_workers` blocks loop over the forward's work list (they are resident from the start of the launch and run beside
+// the tiles' own blocks; behind them they were a tail: measured 425 -> 462 us on S2 with 577 items); the blocks behind them
+// take one tile each.  Idle workers cost ~7 ns each.
+constexpr int SEG_WORKERS = 512;
+
+template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
+    int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+    const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands, int n_workers,
+    SegWs seg, const float* __restrict__ render) {
+    __shared__ StagedBwdMM<ABSGRAD, SH> L;
+    int item = (int)blockIdx.x < n_workers ? (int)blockIdx.x : -1;            // < 0: a tile's own block
+    int t = -1, n_items = 0;
+    if (item < 0) {
+        t = tile_of_block((int)blockIdx.x - n_workers, n_tiles_total, bands, tw);
+        if (t < 0) return;
+    } else {
+        n_items = (int)min(seg.ctl[0], seg.cap);
+    }
+    for (;;) {
+        if (item >= 0) {
+            if (item >= n_items) return;
+            __syncthreads();                             // the walk before may still be reading L
+        }
+        bwd_walk<HAS_BG, ABSGRAD, EXP, SH>(L, t, item, seg, render, W, H, tw, th, splats, tile_offsets, flatten_ids, n_isect_ptr,
+                                           n_tiles_total, backgrounds, alphas, last_ids, v_render, v_alphas, v_splats);
+        if (item < 0) return;
+        item += n_workers;
+    }
+}
+
 }  // namespace mfma_raster
 
 // Which shape: WIDE (four waves per SIMD) where many tiles of similar weight keep every CU busy, DEEP (fastest single wave)
@@ -529,12 +592,20 @@ static long long bwd_wide_min() {
 int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                        const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st) {
+                        const float* v_alphas, int absgrad, float* v_splats, int experiment, const float* render, void* seg_ws,
+                        size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
+    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u};
+    if (seg_ws) {
+        MI_REQUIRE(render != nullptr, "rasterize_bwd: the segment workspace needs the forward's render too");
+        MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_bwd: segment workspace too small");
+    }
+    const int n_workers = seg.ckpt ? SEG_WORKERS : 0;
+    const int grid = raster_grid(n_tiles, tile_width) + n_workers;
 #define LAUNCH_MM(BG, AG, E, SH)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
-              v_render, v_alphas, v_splats, raster_bands())
+              v_render, v_alphas, v_splats, raster_bands(), n_workers, seg, render)
     bool wide = n_gauss >= bwd_wide_min();
 #ifdef MI3DGS_EXPERIMENTS
     if (experiment == 21 || experiment == 22) { wide = experiment == 22; experiment = 0; }

@@ -246,4 +246,38 @@ inline int raster_grid(int n_tiles, int tw) {
 
 struct PixelBasis { float u, v, uu, uv, vv; };
 
+// ---- backward in segments.  One block per tile walks its list serially, so a launch is as long as its heaviest tile: on the
+// reference's wolf.spz (100 k Gaussians, 960 x 720) a few hundred tiles hold thousands of splats each, 84 % of them reached, and
+// rasterize_bwd was 37 % of a real training step.  The forward therefore leaves its per-pixel state (T, r, g, b) at every
+// SEG-entry boundary a tile's block walks past (one work item + one 4 KB checkpoint per boundary, handed out by an atomic
+// counter), and the backward processes the SEG entries in front of each boundary as a tile of their own: transmittance from the
+// checkpoint, "colour behind" = (final colour - checkpoint colour) . v_rgb.  The tile's own block keeps the entries behind its
+// last boundary.  Tiles that never reach SEG entries (all of S2's) leave nothing and cost one branch per batch.
+constexpr int SEG = 512;
+struct SegWs {
+    uint32_t* ctl;        // [0] work items handed out
+    uint32_t* tile_nb;    // [n_tiles] boundaries the forward block of each tile walked past
+    uint4* work;          // [cap] {tile, first list entry of the segment, checkpoint slot of its END boundary, 0}
+    float4* ckpt;         // [cap][256] T, r, g, b per pixel (thread order of the forward block) at the boundary
+    uint32_t cap;
+};
+inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
+    const size_t cap = (size_t)(max_isect / SEG) + 16;       // a boundary has SEG entries of its tile in front of it: at most I / SEG
+    return 512 + (((size_t)n_tiles * 4 + 255) & ~(size_t)255) + cap * (16 + BLOCK * 16);
+}
+// both rasterisers derive the same views from (n_tiles, bytes)
+inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {
+    const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255;
+    const size_t fixed = 512 + nb_bytes;
+    if (bytes < fixed + (16 + BLOCK * 16)) return false;
+    const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
+    char* b = (char*)base;
+    out->ctl = (uint32_t*)b;
+    out->tile_nb = (uint32_t*)(b + 256);
+    out->work = (uint4*)(b + 256 + nb_bytes);
+    out->ckpt = (float4*)(b + 256 + nb_bytes + ((cap * 16 + 255) & ~(size_t)255));
+    out->cap = (uint32_t)cap;
+    return true;
+}
+
 }  // namespace mfma_raster

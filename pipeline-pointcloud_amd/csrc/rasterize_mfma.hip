@@ -39,8 +39,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
-    int32_t* __restrict__ last_ids, int bands) {
+    int32_t* __restrict__ last_ids, int bands, SegWs seg) {
     __shared__ Staged L;
+    __shared__ uint32_t s_slot;
     const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
     if (t < 0) return;
     const int cam = t / (tw * th);
@@ -59,8 +60,26 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int cur = 0;
     unsigned long long live = wave_ballot(inside);            // lanes still compositing
+    uint32_t nb = 0;                                          // SEG boundaries this block walked past (backward segments)
+    bool seg_on = seg.ckpt != nullptr;
     for (int bs = start; bs < end; bs += BLOCK) {
         if (!__syncthreads_or(live != 0ull)) break;
+        if (seg_on && bs > start && ((bs - start) & (SEG - 1)) == 0) {
+            // somebody composites on beyond this boundary: leave the state for the backward's segment in front of it
+            if (threadIdx.x == 0) {
+                const uint32_t slot = atomicAdd(&seg.ctl[0], 1u);
+                s_slot = slot;
+                if (slot < seg.cap) seg.work[slot] = make_uint4((uint32_t)t, (uint32_t)(bs - SEG), slot, 0u);
+            }
+            __syncthreads();
+            const uint32_t slot = s_slot;
+            if (slot < seg.cap) {
+                seg.ckpt[(size_t)slot * BLOCK + threadIdx.x] = make_float4(T, cr, cg, cb);
+                nb++;
+            } else {
+                seg_on = false;           // (can not happen: cap >= I / SEG; the tile's own block then keeps the rest)
+            }
+        }
         {
             // (fetching the list one batch ahead was measured: forward 136.6 -> 149.5 us on the same box; the other
             // blocks of the CU already hide this gather)
@@ -107,6 +126,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
         alphas[pix] = 1.f - T;
         last_ids[pix] = cur;
     }
+    if (seg.ckpt != nullptr && threadIdx.x == 0) seg.tile_nb[t] = nb;
 }
 
 #ifdef MI3DGS_EXPERIMENTS
@@ -321,11 +341,17 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
-                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, hipStream_t st) {
+                          const float* backgrounds, float* render, float* alphas, int32_t* last_ids, void* seg_ws, size_t seg_ws_bytes,
+                          hipStream_t st) {
     using namespace mfma_raster;
+    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u};
+    if (seg_ws) {
+        MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_fwd: segment workspace too small (mi3dgs_raster_seg_workspace_bytes)");
+        MI_HIP(hipMemsetAsync(seg.ctl, 0, 64, st));
+    }
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
-              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands())
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands(), seg)
     if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
 #undef LAUNCH_FWD
     MI_LAUNCH_CHECK();
@@ -335,12 +361,14 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
 int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                        const float* v_alphas, int absgrad, float* v_splats, int experiment, hipStream_t st);
+                        const float* v_alphas, int absgrad, float* v_splats, int experiment, const float* render, void* seg_ws,
+                        size_t seg_ws_bytes, hipStream_t st);
 
 int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
-                          const float* v_alphas, int absgrad, float* v_splats, int mode, long long n_gauss, hipStream_t st) {
+                          const float* v_alphas, int absgrad, float* v_splats, int mode, long long n_gauss, const float* render,
+                          void* seg_ws, size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
     // mode 1: the contraction on the matrix pipe (rasterize_bwd_mm.hip), the product path and the only one of the product
     // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 and 11..14 = variants of the product
@@ -359,5 +387,11 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
     }
 #endif
     return mi_rasterize_bwd_mm(n_tiles, width, height, tile_width, tile_height, n_gauss, splats, isect_offsets, flatten_ids, n_isect_dev,
-                               backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, mode == 1 ? 0 : mode, st);
+                               backgrounds, alphas, last_ids, v_render, v_alphas, absgrad, v_splats, mode == 1 ? 0 : mode, render, seg_ws,
+                               seg_ws_bytes, st);
+}
+
+extern "C" size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect) {
+    if (n_tiles <= 0 || max_isect < 0) return 0;
+    return mfma_raster::seg_ws_bytes_for(n_tiles, max_isect);
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MI3DGS_LIB") or os.path.join(_HERE, "libmi3dgs.so")
 # only by experiments_lib() -- the A/B tools under tools/ and the tests that use a rejected-but-correct variant as a yardstick
 EXP_LIB_PATH = os.path.join(_HERE, "libmi3dgs_exp.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib: Optional[C.CDLL] = None
 _exp_lib: Optional[C.CDLL] = None
@@ -55,8 +55,9 @@ _SIGNATURES = {
     "mi3dgs_async_errors": (_i, [C.POINTER(_u32), _i]),
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),
     "mi3dgs_scan_exclusive_u32": (_i, [_f, _f, _ll, _f, _f, _sz, _f]),
-    "mi3dgs_rasterize_fwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f]),
-    "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _ll, _f]),
+    "mi3dgs_rasterize_fwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _f]),
+    "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _ll, _f, _f, _sz, _f]),
+    "mi3dgs_raster_seg_workspace_bytes": (_sz, [_i, _ll]),
     "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_scale_reg": (_i, [_i, _f, _fl, _fl, _f, _f, _f]),

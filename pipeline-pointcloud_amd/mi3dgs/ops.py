@@ -212,7 +212,21 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     return out
 
 
-def rasterize_fwd(splats, binning, width, height, tile_size=16, backgrounds=None, out=None):
+def raster_seg_workspace(binning, Cn, device, out=None):
+    """The workspace through which rasterize_fwd hands per-pixel checkpoints to rasterize_bwd (include/mi3dgs.h, "Segment
+    workspace"): 4 KB per possible 512-entry boundary, touched only where a tile's list really is that long."""
+    n_tiles = Cn * binning["tile_width"] * binning["tile_height"]
+    nbytes = int(_lib.lib().mi3dgs_raster_seg_workspace_bytes(n_tiles, int(binning["max_isect"])))
+    ws = out.get("seg_ws") if out is not None else None
+    if ws is None or ws.numel() < nbytes or ws.device != device:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if out is not None:
+            out["seg_ws"] = ws
+    return ws
+
+
+def rasterize_fwd(splats, binning, width, height, tile_size=16, backgrounds=None, out=None, seg_ws=None):
+    """seg_ws: a raster_seg_workspace() tensor; hand the same one (and `render`) to rasterize_bwd of this step."""
     Cn = splats.shape[0]
     dev = splats.device
     o = out if out is not None else {}
@@ -227,21 +241,26 @@ def rasterize_fwd(splats, binning, width, height, tile_size=16, backgrounds=None
     _lib.call("mi3dgs_rasterize_fwd", Cn, int(width), int(height), tile_size, binning["tile_width"],
               binning["tile_height"], _p(splats), _p(binning["isect_offsets"]), _p(binning["flatten_ids"]),
               _p(binning["n_isect"]), _p(backgrounds), _p(o["render"]), _p(o["alphas"]), _p(o["last_ids"]),
-              _stream(dev))
+              _p(seg_ws), 0 if seg_ws is None else seg_ws.numel(), _stream(dev))
     return o["render"], o["alphas"], o["last_ids"]
 
 
 def rasterize_bwd(splats, binning, width, height, alphas, last_ids, v_render, v_alphas, tile_size=16,
-                  backgrounds=None, absgrad=False, v_splats=None):
+                  backgrounds=None, absgrad=False, v_splats=None, render=None, seg_ws=None):
     Cn, N = splats.shape[0], splats.shape[1]
     dev = splats.device
     if v_splats is None:
         v_splats = torch.zeros(Cn, N, GRAD_STRIDE, dtype=torch.float32, device=dev)
     _chk(v_render, "v_render", (Cn, height, width, 3)); _chk(v_alphas, "v_alphas", (Cn, height, width, 1))
+    if seg_ws is not None:
+        if render is None:
+            raise ValueError("rasterize_bwd: seg_ws needs the forward's render")
+        _chk(render, "render", (Cn, height, width, 3))
     _lib.call("mi3dgs_rasterize_bwd", Cn, int(width), int(height), tile_size, binning["tile_width"],
               binning["tile_height"], _p(splats), _p(binning["isect_offsets"]), _p(binning["flatten_ids"]),
               _p(binning["n_isect"]), _p(backgrounds), _p(alphas), _p(last_ids), _p(v_render), _p(v_alphas),
-              int(bool(absgrad)), _p(v_splats), int(N), _stream(dev))
+              int(bool(absgrad)), _p(v_splats), int(N), _p(render if seg_ws is not None else None), _p(seg_ws),
+              0 if seg_ws is None else seg_ws.numel(), _stream(dev))
     return v_splats
 
 
@@ -382,23 +401,27 @@ class _Rasterization(torch.autograd.Function):
                                     radius_clip=cfg["radius_clip"], flags=flags)
         binning = bin_tiles(radii, splats, W, H, cfg["tile_size"], want_isect_ids=cfg.get("want_isect_ids", False),
                             want_tiles_per_gauss=cfg.get("want_isect_ids", False))
-        render, alphas, last_ids = rasterize_fwd(splats, binning, W, H, cfg["tile_size"], backgrounds)
-        ctx.cfg, ctx.flags, ctx.binning = cfg, flags, binning
+        # a backward will follow: let the forward leave checkpoints, so that long tile lists are walked in segments
+        seg_ws = raster_seg_workspace(binning, splats.shape[0], splats.device) if cfg.get("segments", True) and any(
+            ctx.needs_input_grad) else None
+        render, alphas, last_ids = rasterize_fwd(splats, binning, W, H, cfg["tile_size"], backgrounds, seg_ws=seg_ws)
+        ctx.cfg, ctx.flags, ctx.binning, ctx.seg_ws = cfg, flags, binning, seg_ws
         ctx.color_mode = COLOR_SH if colors is None else (COLOR_PER_CAMERA if colors.dim() == 3 else COLOR_PER_GAUSSIAN)
         ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, backgrounds, radii, splats,
-                              alphas, last_ids)
-        cfg["_meta"].update(radii=radii, splats=splats, last_ids=last_ids, **binning)
+                              alphas, last_ids, render)
+        cfg["_meta"].update(radii=radii, splats=splats, last_ids=last_ids, seg_ws=seg_ws, **binning)
         ctx.mark_non_differentiable(last_ids)
         return render, alphas, last_ids
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _):
         (means, quats, scales, opacities, sh0, shN, viewmats, Ks, backgrounds, radii, splats, alphas,
-         last_ids) = ctx.saved_tensors
+         last_ids, render) = ctx.saved_tensors
         cfg = ctx.cfg
         W, H = cfg["width"], cfg["height"]
         v_splats = rasterize_bwd(splats, ctx.binning, W, H, alphas, last_ids, v_render.contiguous(),
-                                 v_alphas.contiguous(), cfg["tile_size"], backgrounds, cfg["absgrad"])
+                                 v_alphas.contiguous(), cfg["tile_size"], backgrounds, cfg["absgrad"],
+                                 render=render, seg_ws=ctx.seg_ws)
         cfg["_meta"]["v_splats"] = v_splats
         g = project_bwd(means, quats, scales, opacities, viewmats, Ks, W, H, radii, splats, v_splats, sh0=sh0,
                         shN=shN, color_mode=ctx.color_mode, sh_degree=cfg["sh_degree"], eps2d=cfg["eps2d"],
@@ -412,7 +435,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width: 
                   sh_degree: Optional[int] = None, packed: bool = False, tile_size: int = 16,
                   backgrounds: Optional[torch.Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
                   absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32,
-                  want_isect_ids: bool = False):
+                  want_isect_ids: bool = False, segments: bool = True):
     """Drop-in for gsplat `rasterization()` (same argument names and meaning).
 
     means[N,3], quats[N,4] (wxyz, any norm), scales[N,3] (exp'd), opacities[N] (sigmoid'd),
@@ -448,7 +471,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width: 
     meta: Dict = {}
     cfg = dict(width=int(width), height=int(height), tile_size=tile_size, sh_degree=int(sh_degree or 0),
                eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
-               antialiased=rasterize_mode == "antialiased", absgrad=absgrad, want_isect_ids=want_isect_ids,
+               antialiased=rasterize_mode == "antialiased", absgrad=absgrad, want_isect_ids=want_isect_ids, segments=segments,
                _meta=meta)
     render, alphas, _ = _Rasterization.apply(means.contiguous(), quats.contiguous(), scales.contiguous(),
                                              opacities.contiguous(), sh0, shN, cols, viewmats.contiguous(),

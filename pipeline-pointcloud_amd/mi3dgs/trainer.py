@@ -79,6 +79,8 @@ class TrainConfig:
     tight_tiles: bool = True
     # capacity mode only: count and emit fused in one chained pass (mi3dgs_bin_tiles)
     fused_binning: bool = True
+    # the backward walks tile lists longer than 512 entries in segments, from checkpoints the forward leaves (include/mi3dgs.h)
+    raster_segments: bool = True
     # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
     # gradients for its all-reduce and switches this off)
     fuse_adam: bool = True
@@ -253,7 +255,7 @@ class Trainer:
         lr_means = c.lr_means * c.scene_scale * (c.lr_means_final_ratio ** t)
         return (lr_means, c.lr_quats, c.lr_scales, c.lr_opacities, c.lr_sh0, c.lr_shN)
 
-    def _forward(self, viewmat, K, sh_degree, background=None, exact_isect=False):
+    def _forward(self, viewmat, K, sh_degree, background=None, exact_isect=False, segments=False):
         m, n = self.model, self._n()
         radii, splats = self.radii[:, :n], self.splats[:, :n]
         cap = self.cfg.max_isect
@@ -268,7 +270,10 @@ class Trainer:
                                 fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True, want_tile_keys=False)
         if self.cfg.auto_isect_capacity and self.cfg.max_isect is None:
             torch.maximum(self._isect_peak, binning["n_isect"], out=self._isect_peak)
-        render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out)
+        # training steps: the forward leaves checkpoints so that the backward walks long tile lists in segments
+        self._seg_ws = ops.raster_seg_workspace(binning, 1, self.device, self.raster_out) if segments else None
+        render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out,
+                                                     seg_ws=self._seg_ws)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids
 
@@ -296,13 +301,13 @@ class Trainer:
         bg = None
         if c.random_background:
             bg = torch.rand(1, 3, generator=self.dev_gen, device=self.device)      # (was drawn on the host and copied every step)
-        radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg)
+        radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg, segments=c.raster_segments)
         sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch)
         ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
         v_splats = self.v_splats[:, :n]
         v_splats.zero_()
         ops.rasterize_bwd(splats, binning, self.W, self.H, alphas, last_ids, self.v_render, self.v_alphas, 16, bg,
-                          c.absgrad, v_splats)
+                          c.absgrad, v_splats, render=render, seg_ws=self._seg_ws)
         track = c.densify and self.step_count < c.refine_stop_iter
         stats = {k: v[:n] for k, v in self.stats.items()} if track else None
         sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0

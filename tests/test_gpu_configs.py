@@ -35,28 +35,39 @@ def _ops():
     return ops
 
 
-def _oracle_fwd_bwd(A, viewmats, Ks, W, H, wr, wa, sh_degree=3, bg=None, sort_depths=None):
+def _oracle_fwd_bwd(A, viewmats, Ks, W, H, wr, wa, sh_degree=3, bg=None, lists_from=None, mask_marginal=False):
     """float64 oracle, one camera at a time (bounds the autograd graph); returns renders, alphas and the
     gradients of sum(render * wr) + sum(alpha * wa) for the five parameter groups.
-    sort_depths [C, N] (optional): the float32 depths to build the tile-list sort keys from, instead of the oracle's own float64
-    depths rounded to float32 -- the list ORDER is a discrete decision taken on float32 depth bits (gsplat's keys and this
-    library's alike), and two depths one ulp apart in float32 arithmetic can round the other way from float64."""
+
+    The reference takes three kinds of DISCRETE decisions on float32 bits, and a float64 oracle can take each of them the other
+    way without either side being wrong; on a 2 M-Gaussian frame every kind occurs.  None of them is excused per Gaussian:
+      lists_from = (means2d [C,N,2], radii [C,N,2], depths [C,N]) float32, the library's own records: the oracle builds its
+        tile lists (tile rectangle of a splat, order inside a tile) from these values instead of its float64 ones rounded;
+      mask_marginal: pixels where some reached splat's `alpha < 1/255 -> skip` test is closer to its threshold than float32
+        resolves (oracle/gs_oracle.py rasterize_to_pixels, `marginal`) get weight ZERO in the test's loss, on both sides; the
+        mask [C,H,W] is returned as a fourth value and the caller runs the library with the same masked weights."""
     leaves = {k: v.clone().double().requires_grad_(True) for k, v in A.items()}
-    rs, als = [], []
+    rs, als, masks = [], [], []
     orig = O.isect_tiles
     try:
         for c in range(viewmats.shape[0]):
-            if sort_depths is not None:
-                O.isect_tiles = (lambda m2d, rad, dep, *a, _c=c, **k: orig(m2d, rad, sort_depths[_c:_c + 1].to(dep), *a, **k))
+            if lists_from is not None:
+                m32, r32, d32 = (t[c:c + 1] for t in lists_from)
+                O.isect_tiles = (lambda m2d, rad, dep, *a, _m=m32, _r=r32, _d=d32, **k: orig(_m.to(m2d), _r.to(rad), _d.to(dep), *a, **k))
+            marg = {} if mask_marginal else None
             r, a, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["sh"],
                                       viewmats[c:c + 1].double(), Ks[c:c + 1].double(), W, H, sh_degree=sh_degree,
-                                      backgrounds=None if bg is None else bg[c:c + 1].double())
-            ((r * wr[c:c + 1]).sum() + (a * wa[c:c + 1]).sum()).backward()
+                                      backgrounds=None if bg is None else bg[c:c + 1].double(), marginal=marg)
+            keep = 1.0 if marg is None else (~marg["alpha_skip"])[..., None].double()
+            ((r * wr[c:c + 1] * keep).sum() + (a * wa[c:c + 1] * keep).sum()).backward()
             rs.append(r.detach())
             als.append(a.detach())
+            if marg is not None:
+                masks.append(marg["alpha_skip"])
     finally:
         O.isect_tiles = orig
-    return torch.cat(rs), torch.cat(als), {k: v.grad for k, v in leaves.items()}
+    out = (torch.cat(rs), torch.cat(als), {k: v.grad for k, v in leaves.items()})
+    return out + (torch.cat(masks),) if mask_marginal else out
 
 
 def _hip_fwd_bwd(A, viewmats, Ks, W, H, wr, wa, dev, sh_degree=3, bg=None):
@@ -226,25 +237,28 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
         wr = torch.randn(1, ch, cw, 3, generator=g, dtype=torch.float64)
         wa = torch.randn(1, ch, cw, 1, generator=g, dtype=torch.float64)
         bg = torch.rand(1, 3, generator=g, dtype=torch.float64)
-        r, a, gr, meta = _hip_fwd_bwd(A, vm, Kc, cw, ch, wr, wa, dev, bg=bg)
-        # The oracle builds its tile lists from the SAME float32 depth values the library sorted by (the splat records' depth
-        # slot): two thousand splats deep, a few hundred pairs of depths differ by an ulp between float32 arithmetic and
-        # float64-then-rounded, and where such a pair overlaps on screen the two orders give each splat another transmittance --
-        # a discrete decision, not an arithmetic error.  Round 2 set "the eight worst Gaussians" aside for it; with the order
-        # shared nothing is set aside and every Gaussian is held to 2e-3.
+        # first pass of the library: the float32 records its lists were built from (centres, radii, depths)
+        _, _, _, meta = _hip_fwd_bwd(A, vm, Kc, cw, ch, wr, wa, dev, bg=bg)
         sp32 = meta["splats"][0].cpu()[idx]
-        d64 = proj64[2][0][idx]
-        moved = int((torch.argsort(torch.argsort(sp32[:, 9].double(), stable=True)) != torch.argsort(torch.argsort(d64, stable=True))).sum())
-        r_ref, a_ref, g_ref = _oracle_fwd_bwd({k: v[idx] for k, v in A.items()}, vm, Kc, cw, ch, wr, wa, bg=bg,
-                                              sort_depths=sp32[None, :, 9].double())
-        _check_images(r, a, r_ref, a_ref, mean_tol=1e-4, q_tol=5e-3, max_tol=5e-2)
+        rad32 = meta["radii"][0].cpu()[idx]
+        vis64 = (radii[0][idx] > 0).all(-1)
+        assert int(((rad32 > 0).all(-1) != vis64).sum()) == 0
+        r_ref, a_ref, g_ref, mask = _oracle_fwd_bwd({k: v[idx] for k, v in A.items()}, vm, Kc, cw, ch, wr, wa, bg=bg,
+                                                    lists_from=(sp32[None, :, 0:2], rad32[None], sp32[None, :, 9]), mask_marginal=True)
+        n_masked = int(mask.sum())
+        assert n_masked <= 0.002 * cw * ch, (kind, (x0, y0), "pixels with a float32-unresolvable 1/255 decision:", n_masked)
+        keep = (~mask)[..., None].double()
+        # second pass: the same loss as the oracle's -- every pixel whose decisions float32 resolves, every Gaussian held to 2e-3
+        r, a, gr, meta = _hip_fwd_bwd(A, vm, Kc, cw, ch, wr * keep, wa * keep, dev, bg=bg)
+        _check_images(r * keep.float(), a * keep.float(), r_ref * keep, a_ref * keep, mean_tol=1e-4, q_tol=2e-3, max_tol=5e-3)
         assert a_ref.mean() > 0.05
         for k in ("means", "quats", "scales", "opacities", "sh"):
             e_all = rel_err(gr[k][idx], g_ref[k])
-            assert e_all < 2e-3, (kind, (x0, y0), k, e_all, "list positions that differ between float32 and float64 depths:", moved)
+            assert e_all < 2e-3, (kind, (x0, y0), k, e_all, "masked pixels:", n_masked)
             rest = gr[k].clone()
             rest[idx] = 0
             assert float(rest.norm()) <= 1e-3 * float(gr[k].norm()), (k, "gradient outside the oracle's visible set")
+        wr, wa = wr * keep, wa * keep
         # the rasteriser alone: the oracle's compositing and autograd on the HIP projection's own records
         sp = meta["splats"][0].cpu()[idx].double()
         leaves = [sp[None, :, a:b].clone().requires_grad_(True) for a, b in ((0, 2), (2, 5), (6, 9))]
@@ -255,7 +269,7 @@ def test_oracle_on_camera_crops_of_the_full_scene(dev, kind, cam, crops):
                                           O.isect_offset_encode(ids2, 1, tw, th), flat2, backgrounds=bg)
         ((r2 * wr).sum() + (a2 * wa).sum()).backward()
         vs = meta["v_splats"][0].cpu()[idx].double()
-        assert (r.double() - r2.detach()).abs().max() < 2e-3
+        assert ((r.double() - r2.detach()) * keep).abs().max() < 2e-3
         for nm, got, ref in (("mean2d", vs[:, 0:2], leaves[0].grad[0]), ("conic", vs[:, 2:5], leaves[1].grad[0]),
                              ("opacity", vs[:, 5], op.grad[0]), ("colour", vs[:, 6:9], leaves[2].grad[0])):
             assert rel_err(got, ref) < 1e-3, (kind, (x0, y0), "rasteriser only", nm, rel_err(got, ref))
@@ -311,7 +325,7 @@ def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad
     try:
         ops._lib.exp_call("mi3dgs_rasterize_bwd", 1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
                           ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(a), ops._p(l), ops._p(vr), ops._p(va),
-                          int(absgrad), ops._p(rs_out), int(splats.shape[1]), ops._stream(dev))
+                          int(absgrad), ops._p(rs_out), int(splats.shape[1]), None, None, 0, ops._stream(dev))
         torch.cuda.synchronize()
     finally:
         ex.mi3dgs_debug_set_raster_mode(1)

@@ -237,6 +237,48 @@ def test_rasterization_backward_matches_autograd_oracle(dev, mode, bg, sh_degree
         assert e < 2e-3, (k, e)
 
 
+@pytest.mark.parametrize("absgrad,bg,n_views", [(False, True, 1), (True, False, 2)])
+def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, bg, n_views):
+    """Tiles whose lists run to thousands of entries that pixels really reach (faint splats): the forward leaves checkpoints
+    at its 512-entry boundaries and the backward walks the segments as work items of their own.  Held to the autograd oracle
+    like every other backward, and to the one-block-per-tile walk of the same library (segments=False)."""
+    import mi3dgs
+    sc = small_scene(n=8000, seed=21, big=True, width=64, height=48, n_views=n_views)
+    g = torch.Generator().manual_seed(5)
+    sc.params["opacities"] = torch.rand(8000, generator=g) * 1.5 - 5.0          # alpha 0.7 .. 3 %: lists are walked deep
+    sc.params["opacities"][:60] = 1.0                                         # and a few solid ones in between
+    A = activated(sc.params)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in A.items()}
+    bgs = torch.rand(n_views, 3, generator=g).double() if bg else None
+    r_ref, a_ref, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["sh"],
+                                      sc.viewmats.double(), sc.Ks.double(), sc.width, sc.height, sh_degree=3, backgrounds=bgs)
+    wr = torch.randn(r_ref.shape, generator=g).double()
+    wa = torch.randn(a_ref.shape, generator=g).double()
+    ((r_ref * wr).sum() + (a_ref * wa).sum()).backward()
+    grads, metas = [], []
+    for segments in (True, False):
+        gl = {k: v.detach().float().to(dev).requires_grad_(True) for k, v in A.items()}
+        r, a, meta = mi3dgs.rasterization(gl["means"], gl["quats"], gl["scales"], gl["opacities"], gl["sh"], sc.viewmats.to(dev),
+                                          sc.Ks.to(dev), sc.width, sc.height, sh_degree=3,
+                                          backgrounds=None if bgs is None else bgs.float().to(dev), absgrad=absgrad,
+                                          segments=segments)
+        ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
+        grads.append({k: gl[k].grad.cpu() for k in gl})
+        metas.append(meta)
+    # the case is what it claims to be: every tile's list is thousands long and hundreds of boundaries were walked past
+    off = metas[0]["isect_offsets"].flatten().cpu()
+    n_items = int(metas[0]["seg_ws"][:4].view(torch.int32)[0].item())
+    assert int(off.diff().max()) > 3000 and n_items >= 20 * n_views and metas[1]["seg_ws"] is None, (int(off.diff().max()), n_items)
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        e_seg, e_ser = rel_err(grads[0][k], leaves[k].grad), rel_err(grads[1][k], leaves[k].grad)
+        assert e_seg < 2e-3 and e_ser < 2e-3, (k, e_seg, e_ser)
+        assert rel_err(grads[0][k], grads[1][k]) < 2e-4, (k, rel_err(grads[0][k], grads[1][k]))
+    if absgrad:
+        v0, v1 = metas[0]["v_splats"], metas[1]["v_splats"]
+        assert rel_err(v0[..., 9:11].cpu(), v1[..., 9:11].cpu()) < 2e-4
+        assert (v0[..., 9] * (1 + 1e-4) + 1e-9 >= v0[..., 0].abs()).all()
+
+
 def test_absgrad_record(dev):
     sc = small_scene(n=200, seed=9, big=True)
     (_, _, _, _), (r, a, meta, gl) = _run_both(sc, dev, 3, True, "classic", absgrad=True)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--absgrad", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--modes", nargs="*", type=int, default=None, help="raster mode per lib (experiments builds), default 1")
+    ap.add_argument("--seg", nargs="*", type=int, default=None, help="1 = with the segment workspace, per lib (ABI >= 5)")
     a = ap.parse_args()
     from mi3dgs import _lib, ops, scenes
     dev = torch.device("cuda:0")
@@ -59,8 +60,16 @@ def main():
             fn.restype, fn.argtypes = _lib._SIGNATURES[name]
         h.mi3dgs_abi_version.restype = C.c_int
         h._abi = h.mi3dgs_abi_version()
-        if h._abi < 4:           # round-2 builds: no n_gaussians argument
-            h.mi3dgs_rasterize_bwd.argtypes = _lib._SIGNATURES["mi3dgs_rasterize_bwd"][1][:-2] + [C.c_void_p]
+        sig_b, sig_f = _lib._SIGNATURES["mi3dgs_rasterize_bwd"][1], _lib._SIGNATURES["mi3dgs_rasterize_fwd"][1]
+        if h._abi < 5:           # before the segment workspace
+            h.mi3dgs_rasterize_fwd.argtypes = sig_f[:-3] + [C.c_void_p]
+            h.mi3dgs_rasterize_bwd.argtypes = sig_b[:-4] + [C.c_void_p]
+        if h._abi < 4:           # round-2 builds: no n_gaussians argument either
+            h.mi3dgs_rasterize_bwd.argtypes = sig_b[:-5] + [C.c_void_p]
+        h._seg = None
+        if a.seg and a.seg[i]:
+            assert h._abi >= 5
+            h._seg = ops.raster_seg_workspace(b, 1, dev)
         if a.modes:
             assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
         handles.append(h)
@@ -68,18 +77,26 @@ def main():
     def bwd_args(h, out):
         head = (1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]), ops._p(b["flatten_ids"]),
                 ops._p(b["n_isect"]), ops._p(bg), ops._p(al), ops._p(last), ops._p(vr), ops._p(va), int(a.absgrad), ops._p(out))
+        if h._abi >= 5:
+            return head + (N, ops._p(h._r) if h._seg is not None else None, ops._p(h._seg), 0 if h._seg is None else h._seg.numel(), st)
         return head + ((N, st) if h._abi >= 4 else (st,))
 
     def fwd(h, o):
         rc = h.mi3dgs_rasterize_fwd(1, W, H, 16, b["tile_width"], b["tile_height"], ops._p(splats), ops._p(b["isect_offsets"]),
-                                    ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(o[0]), ops._p(o[1]), ops._p(o[2]), st)
+                                    ops._p(b["flatten_ids"]), ops._p(b["n_isect"]), ops._p(bg), ops._p(o[0]), ops._p(o[1]), ops._p(o[2]),
+                                    *((ops._p(h._seg), 0 if h._seg is None else h._seg.numel(), st) if h._abi >= 5 else (st,)))
         assert rc == 0, h.mi3dgs_last_error()
+        h._r = o[0]
 
     outs = [torch.zeros(1, N, 16, device=dev) for _ in handles]
     fo = [(torch.empty_like(r), torch.empty_like(al), torch.empty_like(last)) for _ in handles]
     tb = [[] for _ in handles]
     tf = [[] for _ in handles]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i, h in enumerate(handles):          # a forward of its own first: a segmented backward reads what it left
+        if a.modes:
+            assert h.mi3dgs_debug_set_raster_mode(a.modes[i]) == 0, h.mi3dgs_last_error()
+        fwd(h, fo[i])
     for rep in range(a.reps + 2):
         for i, h in enumerate(handles):
             for fn, arg, acc in (("bwd", outs[i], tb[i]), (fwd, fo[i], tf[i])):
@@ -103,7 +120,11 @@ def main():
         d = outs[i].double()
         cols = 11 if a.absgrad else 9
         err = float((d[..., :cols] - ref[..., :cols]).norm() / ref[..., :cols].norm())
-        res.append(dict(lib=path, mode=(a.modes[i] if a.modes else 1), bwd_us_median=sorted(tb[i])[len(tb[i]) // 2], bwd_us_min=min(tb[i]),
+        if handles[i]._seg is not None:
+            res_items = int(handles[i]._seg[:4].view(torch.int32)[0].item())
+        else:
+            res_items = None
+        res.append(dict(lib=path, mode=(a.modes[i] if a.modes else 1), seg_items=res_items, bwd_us_median=sorted(tb[i])[len(tb[i]) // 2], bwd_us_min=min(tb[i]),
                         fwd_us_median=sorted(tf[i])[len(tf[i]) // 2], rel_diff_vs_first=err,
                         fwd_equal_first=bool(torch.equal(fo[i][0], fo[0][0]) and torch.equal(fo[i][2], fo[0][2]))))
     print(json.dumps(dict(scene=a.scene, absgrad=a.absgrad, n_isect=int(b["n_isect"].item()), results=res), indent=1), flush=True)
