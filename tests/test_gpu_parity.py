@@ -289,10 +289,13 @@ def test_absgrad_record(dev):
 
 
 # -------------------------------------------------------------------------------- loss
-def test_loss_fwd_bwd_matches_oracle(dev):
+@pytest.mark.parametrize("C,H,W", [(2, 45, 70), (1, 131, 301), (3, 17, 9), (1, 80, 86)])
+def test_loss_fwd_bwd_matches_oracle(dev, C, H, W):
+    """Sizes: fewer columns than one block owns; several column blocks and several row strips with ragged ends (131 rows in
+    strips of 16, 903 floats per row in blocks of 256); an image smaller than the blur window; 258 floats per row (a second
+    column block that owns two float-columns)."""
     ops = _ops()
     g = torch.Generator().manual_seed(3)
-    C, H, W = 2, 45, 70          # not multiples of the tile: exercises the zero padding
     a = torch.rand(C, H, W, 3, generator=g)
     b = (a + 0.2 * torch.randn(C, H, W, 3, generator=g)).clamp(0, 1)
     ad = a.double().requires_grad_(True)
