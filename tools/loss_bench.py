@@ -1,11 +1,11 @@
-"""Same-box timing of the loss kernels: the product library (streaming kernels) against the experiments library with
-MI3DGS_LOSS_TILES=1 (the 32 x 32-tile kernels of rounds 1-2), same inputs, results compared.
+"""Same-box timing of the loss kernels: the product library (32 x 32-tile kernels) against the experiments library with
+MI3DGS_LOSS_STREAM=1 (row-streaming kernels, csrc/loss.hip), same inputs, results compared.
     python tools/loss_bench.py [H W] ..."""
 import json
 import os
 import sys
 
-os.environ["MI3DGS_LOSS_TILES"] = "1"          # read by the experiments library only
+os.environ["MI3DGS_LOSS_STREAM"] = "1"         # read by the experiments library only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pipeline-pointcloud_amd"))
 import torch                                    # noqa: E402
@@ -24,7 +24,7 @@ def main():
         a = torch.rand(1, H, W, 3, generator=g).to(dev)
         b = (a + 0.1 * torch.randn(1, H, W, 3, generator=g).to(dev)).clamp(0, 1)
         res = {}
-        for name, call in (("stream", _lib.call), ("tiles", _lib.exp_call)):
+        for name, call in (("stream", _lib.exp_call), ("tiles", _lib.call)):
             dm = [torch.empty_like(a) for _ in range(3)]
             sums = torch.zeros(2, device=dev)
             v = torch.empty_like(a)
