@@ -300,7 +300,7 @@ namespace mfma_raster {
 
 // One walk of rasterize_bwd: the entries [lo, ...] of tile t's list, back to front, for the block's 256 pixels.
 //   item < 0: the tile's own block -- everything behind the last boundary the forward left (the whole list if it left none);
-//   item >= 0: segment `item` of the work list -- the SEG entries in front of a boundary, state from the forward's checkpoint.
+//   item >= 0: segment `item` of the work list -- the entries in front of a boundary, state from the forward's checkpoint.
 template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
 __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int item, const SegWs& seg, const float* __restrict__ render,
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
@@ -310,11 +310,11 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
     constexpr int STG = SH::STG;
     const bool worker = item >= 0;
-    int seg_lo = 0;
+    int seg_lo = 0, seg_len = 0;
     uint32_t slot_ck = 0;
     if (worker) {
         const uint4 wk = seg.work[item];
-        t = (int)wk.x; seg_lo = (int)wk.y; slot_ck = wk.z;
+        t = (int)wk.x; seg_lo = (int)wk.y; slot_ck = wk.z; seg_len = (int)wk.w;
     }
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
@@ -334,11 +334,11 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     px.uu = px.u * px.u; px.uv = px.u * px.v; px.vv = px.v * px.v;
     int start, end;
     if (worker) {
-        start = seg_lo; end = seg_lo + SEG;
+        start = seg_lo; end = seg_lo + seg_len;
     } else {
         start = tile_offsets[t];
         end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
-        if (seg.ckpt) start += (int)seg.tile_nb[t] * SEG;
+        if (seg.ckpt) start += (int)seg.tile_skip[t];
     }
     RB_STAMP(0, wall_clock64()); RB_STAMP(1, 0ull); RB_STAMP(2, 0ull);
     // the pixel's values do not depend on the tile's range: requested before the range is looked at, so that they travel
@@ -544,7 +544,10 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 // The first `n_workers` blocks loop over the forward's work list (they are resident from the start of the launch and run beside
 // the tiles' own blocks; behind them they were a tail: measured 425 -> 462 us on S2 with 577 items); the blocks behind them
 // take one tile each.  Idle workers cost ~7 ns each.
-constexpr int SEG_WORKERS = 512;
+#ifndef MI_SEG_WORKERS
+#define MI_SEG_WORKERS 512
+#endif
+constexpr int SEG_WORKERS = MI_SEG_WORKERS;
 
 template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
@@ -595,7 +598,7 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
                         const float* v_alphas, int absgrad, float* v_splats, int experiment, const float* render, void* seg_ws,
                         size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
-    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u};
+    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (seg_ws) {
         MI_REQUIRE(render != nullptr, "rasterize_bwd: the segment workspace needs the forward's render too");
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_bwd: segment workspace too small");

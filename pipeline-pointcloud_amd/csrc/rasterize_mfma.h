@@ -249,20 +249,25 @@ struct PixelBasis { float u, v, uu, uv, vv; };
 // ---- backward in segments.  One block per tile walks its list serially, so a launch is as long as its heaviest tile: on the
 // reference's wolf.spz (100 k Gaussians, 960 x 720) a few hundred tiles hold thousands of splats each, 84 % of them reached, and
 // rasterize_bwd was 37 % of a real training step.  The forward therefore leaves its per-pixel state (T, r, g, b) at every
-// SEG-entry boundary a tile's block walks past (one work item + one 4 KB checkpoint per boundary, handed out by an atomic
-// counter), and the backward processes the SEG entries in front of each boundary as a tile of their own: transmittance from the
+// seg-entry boundary a tile's block walks past (one work item + one 4 KB checkpoint per boundary, handed out by an atomic
+// counter), and the backward processes the entries in front of each boundary as a tile of their own: transmittance from the
 // checkpoint, "colour behind" = (final colour - checkpoint colour) . v_rgb.  The tile's own block keeps the entries behind its
-// last boundary.  Tiles that never reach SEG entries (all of S2's) leave nothing and cost one branch per batch.
-constexpr int SEG = 512;
+// last boundary.  Tiles that stop before the first boundary leave nothing and cost one branch per batch.
+// Segment length: 256 or 512 entries, the FORWARD's choice (the backward reads it from the work items).  Shorter segments
+// balance better (S1 146 -> 118 us, wolf 1280 x 720 199 -> 153) but every item has a fixed cost, which shows where lists are long
+// and evenly long, i.e. where nothing needed balancing (S2: 577 items at 512 are free, 2 373 items at 256 cost 20 us).  The
+// capacity per tile is the host-side proxy for that: above 1 024 entries per tile the forward uses 512.
+constexpr int SEG_MIN = 256;              // = BLOCK: the forward can only stop at its batch boundaries
 struct SegWs {
     uint32_t* ctl;        // [0] work items handed out
-    uint32_t* tile_nb;    // [n_tiles] boundaries the forward block of each tile walked past
-    uint4* work;          // [cap] {tile, first list entry of the segment, checkpoint slot of its END boundary, 0}
+    uint32_t* tile_skip;  // [n_tiles] entries at the head of each tile's list that belong to work items (its own block starts behind them)
+    uint4* work;          // [cap] {tile, first list entry of the segment, checkpoint slot of its END boundary, entries in the segment}
     float4* ckpt;         // [cap][256] T, r, g, b per pixel (thread order of the forward block) at the boundary
     uint32_t cap;
+    uint32_t seg;         // entries per segment of this call (forward only)
 };
 inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
-    const size_t cap = (size_t)(max_isect / SEG) + 16;       // a boundary has SEG entries of its tile in front of it: at most I / SEG
+    const size_t cap = (size_t)(max_isect / SEG_MIN) + 16;       // a boundary has >= SEG_MIN entries of its tile in front of it
     return 512 + (((size_t)n_tiles * 4 + 255) & ~(size_t)255) + cap * (16 + BLOCK * 16);
 }
 // both rasterisers derive the same views from (n_tiles, bytes)
@@ -273,10 +278,11 @@ inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {
     const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
     char* b = (char*)base;
     out->ctl = (uint32_t*)b;
-    out->tile_nb = (uint32_t*)(b + 256);
+    out->tile_skip = (uint32_t*)(b + 256);
     out->work = (uint4*)(b + 256 + nb_bytes);
     out->ckpt = (float4*)(b + 256 + nb_bytes + ((cap * 16 + 255) & ~(size_t)255));
     out->cap = (uint32_t)cap;
+    out->seg = ((cap - 16) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) > 1024) ? 512u : 256u;
     return true;
 }
 

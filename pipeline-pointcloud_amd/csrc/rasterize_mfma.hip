@@ -60,16 +60,16 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int cur = 0;
     unsigned long long live = wave_ballot(inside);            // lanes still compositing
-    uint32_t nb = 0;                                          // SEG boundaries this block walked past (backward segments)
+    uint32_t nb = 0;                                          // segment boundaries this block walked past (backward segments)
     bool seg_on = seg.ckpt != nullptr;
     for (int bs = start; bs < end; bs += BLOCK) {
         if (!__syncthreads_or(live != 0ull)) break;
-        if (seg_on && bs > start && ((bs - start) & (SEG - 1)) == 0) {
+        if (seg_on && bs > start && ((bs - start) & (int)(seg.seg - 1)) == 0) {
             // somebody composites on beyond this boundary: leave the state for the backward's segment in front of it
             if (threadIdx.x == 0) {
                 const uint32_t slot = atomicAdd(&seg.ctl[0], 1u);
                 s_slot = slot;
-                if (slot < seg.cap) seg.work[slot] = make_uint4((uint32_t)t, (uint32_t)(bs - SEG), slot, 0u);
+                if (slot < seg.cap) seg.work[slot] = make_uint4((uint32_t)t, (uint32_t)bs - seg.seg, slot, seg.seg);
             }
             __syncthreads();
             const uint32_t slot = s_slot;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
                 seg.ckpt[(size_t)slot * BLOCK + threadIdx.x] = make_float4(T, cr, cg, cb);
                 nb++;
             } else {
-                seg_on = false;           // (can not happen: cap >= I / SEG; the tile's own block then keeps the rest)
+                seg_on = false;           // (can not happen: cap >= I / 256; the tile's own block then keeps the rest)
             }
         }
         {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
         alphas[pix] = 1.f - T;
         last_ids[pix] = cur;
     }
-    if (seg.ckpt != nullptr && threadIdx.x == 0) seg.tile_nb[t] = nb;
+    if (seg.ckpt != nullptr && threadIdx.x == 0) seg.tile_skip[t] = nb * seg.seg;
 }
 
 #ifdef MI3DGS_EXPERIMENTS
@@ -344,7 +344,7 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           const float* backgrounds, float* render, float* alphas, int32_t* last_ids, void* seg_ws, size_t seg_ws_bytes,
                           hipStream_t st) {
     using namespace mfma_raster;
-    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u};
+    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (seg_ws) {
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_fwd: segment workspace too small (mi3dgs_raster_seg_workspace_bytes)");
         MI_HIP(hipMemsetAsync(seg.ctl, 0, 64, st));

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--modes", nargs="*", type=int, default=None, help="raster mode per lib (experiments builds), default 1")
     ap.add_argument("--seg", nargs="*", type=int, default=None, help="1 = with the segment workspace, per lib (ABI >= 5)")
+    ap.add_argument("--wolf-size", nargs=2, type=int, default=[960, 720], help="image size of the wolf scene")
     a = ap.parse_args()
     from mi3dgs import _lib, ops, scenes
     dev = torch.device("cuda:0")
@@ -33,9 +34,10 @@ def main():
         P = load_wolf()
         centre = P["means"].median(0).values
         ext = float((P["means"] - centre).abs().quantile(0.99))
-        P = scenes.add_backdrop(scenes.Scene("wolf", P, None, None, 960, 720), 12000, 9.0 * ext, tuple(centre.tolist())).params
+        WW, WH = a.wolf_size
+        P = scenes.add_backdrop(scenes.Scene("wolf", P, None, None, WW, WH), 12000, 9.0 * ext, tuple(centre.tolist())).params
         eye = centre + torch.tensor([3.2 * ext * math.cos(0.6) * math.cos(0.3), -3.2 * ext * math.sin(0.3), 3.2 * ext * math.sin(0.6) * math.cos(0.3)])
-        sc = scenes.Scene("wolf", P, scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0))[None], scenes._intrinsics(1.25 * 960, 960, 720)[None], 960, 720)
+        sc = scenes.Scene("wolf", P, scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0))[None], scenes._intrinsics(1.25 * WW, WW, WH)[None], WW, WH)
         a.cam = 0
     else:
         sc = scenes.make_scene(a.scene)
