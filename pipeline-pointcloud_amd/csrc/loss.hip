@@ -273,49 +273,72 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
 
 #ifdef MI3DGS_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------
-// Streaming kernels (round 3).  An image row is a 1-D array of W * 3 floats (interleaved RGB); the 11-tap blur along x touches
-// floats c - 15, c - 12, ..., c + 15 whatever channel c belongs to, and the blur along y stays inside one float-column.  A block
-// owns SCOLS float-columns and walks down a strip of R rows:
-//   per input row: every thread stages (u, v, u^2 + v^2, u v) of one float as one float4 in LDS (double-buffered row, ONE
-//     barrier per row), reads the eleven taps of its own column as float4s, and has the horizontally blurred moments h;
-//   vertical blur without LDS: h is added, weighted, to the eleven output rows it belongs to (44 accumulators in registers,
-//     rotating -- the loop is unrolled by 11 so that their indices are static); the output row that just received its last
-//     tap is finished: SSIM and its three derivative maps, stored coalesced.
-// Experiments build only (MI3DGS_LOSS_STREAM=1): measured against the tile kernels on one box, 1080p, it is no faster --
-// forward 69 vs 73 us, backward 65 vs 51 us (profiles/r03_loss_stream_ab.txt).  Both designs issue ~255-275 instructions per
-// pixel-channel against 44 packed FMAs of arithmetic; with ONE output per thread and row, every address, wait and barrier of a
-// row is paid per output, and a strip is a long serial chain (391 blocks for 256 CUs at 1080p).  What would pay is four
-// outputs per thread (14 tap reads per 4 outputs, 176 accumulators) in wave-private rows; not built.
-constexpr int SCOLS = 256;                  // float-columns (threads) per block
-constexpr int SHALO = 15;                   // 5 pixels x 3 interleaved channels
-constexpr int SROW = SCOLS + 2 * SHALO;
+// Wave-private strips (round 3; experiments build, MI3DGS_LOSS_STREAM=1, until it beats the tile kernels).
+// An image row is a 1-D array of W * 3 floats (interleaved RGB): the 11-tap blur along x touches floats c - 15, c - 12, ..., c + 15
+// whatever channel c is, and the blur along y stays inside one float-column.  ONE WAVE owns 126 float-columns and walks down a
+// strip of R rows; nothing is shared between waves, so there is no block barrier anywhere:
+//   staging: 39 lanes load 16 bytes of each image row, form (u, v, u^2 + v^2, u v) per float and store them as float4s in the
+//     wave's LDS row (LDS serves a wave in order: the row is complete before the wave's own reads of it);
+//   horizontal: a lane owns TWO outputs of one channel at neighbouring pixels (floats c and c + 3) and reads the 12 taps they
+//     share once;
+//   vertical, without LDS: the horizontally blurred moments are added, weighted, to the eleven output rows they belong to
+//     (2 x 44 register accumulators, shifted by one row per input row -- for free, an FMA names its destination); the output row
+//     that just received its last tap is finished: SSIM and its three derivative maps, stored.
+// First attempt of the round (one output per thread, 256-thread blocks, one barrier per row): 69 / 65 us against the tile
+// kernels' 73 / 51 (profiles/r03_loss_stream_ab.txt) -- every address, wait and barrier of a row was paid per output.
+constexpr int SHALO = 15;                      // 5 pixels x 3 interleaved channels
+constexpr int WO = 2;                          // outputs per lane
+constexpr int WCOLS = 63 * WO;                 // float-columns per wave (lane 63 idles: 63 = 21 pixel pairs x 3 channels)
+constexpr int WROW = WCOLS + 2 * SHALO;        // 156 staged floats per row
+constexpr int WLOAD = WROW / 4;                // 39 lanes load a float4 each
+static_assert(WROW % 4 == 0, "staging by float4");
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte load from a 4-byte-aligned address
 
-struct StripGeom {
-    int c, cs, chalo, y_in0, n_out, n_in;
-    bool ok_s, ok_h, ok_o;
+struct WaveStrip {
+    int lane, c0, y_in0, n_out, n_in, sc, ob;
+    bool s_on, s_vec, o_on[WO];
 };
 
-__device__ __forceinline__ StripGeom strip_geom(int H, int W3, int R) {
-    StripGeom g;
-    const int c0 = blockIdx.x * SCOLS, y0 = blockIdx.y * R, t = threadIdx.x;
-    g.c = c0 + t;
-    g.cs = c0 - SHALO + t;                        // the float this thread stages
-    g.chalo = c0 - SHALO + SCOLS + t;             // threads 0..29 stage the right halo too
-    g.ok_s = g.cs >= 0 && g.cs < W3;
-    g.ok_h = t < 2 * SHALO && g.chalo < W3;
-    g.ok_o = g.c < W3;
+__device__ __forceinline__ WaveStrip wave_strip(int H, int W3, int R) {
+    WaveStrip g;
+    g.lane = threadIdx.x;
+    g.c0 = blockIdx.x * WCOLS;
+    const int y0 = blockIdx.y * R;
     g.y_in0 = y0 - HALO;
     g.n_out = min(R, H - y0);
     g.n_in = g.n_out + 2 * HALO;
+    g.sc = g.c0 - SHALO + 4 * g.lane;                       // first of the four floats this lane stages
+    g.s_on = g.lane < WLOAD;
+    g.s_vec = g.s_on && g.sc >= 0 && g.sc + 3 < W3;
+    const int grp = g.lane / 3;
+    g.ob = 6 * grp + (g.lane - 3 * grp);                    // first output float, relative to c0; taps: staged floats ob + 3 m
+#pragma unroll
+    for (int o = 0; o < WO; o++) g.o_on[o] = g.lane < 63 && g.c0 + g.ob + 3 * o < W3;
     return g;
 }
 
-// value of input row i of the strip at float-column col (zero outside the image: 'same' zero padding)
-__device__ __forceinline__ float strip_load(const float* __restrict__ img, const StripGeom& g, int H, int W3, int i, int col, bool col_ok) {
+// the four floats of input row i this lane stages (zero outside the image: 'same' zero padding)
+__device__ __forceinline__ float4 strip_load4(const float* __restrict__ img, const WaveStrip& g, int H, int W3, int i) {
     const int y = g.y_in0 + i;
-    const bool ok = col_ok && y >= 0 && y < H && i < g.n_in;
-    const float v = img[ok ? y * W3 + col : 0];
-    return ok ? v : 0.f;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < g.n_in && y >= 0 && y < H) {                    // wave-uniform
+        const float* p = img + (size_t)y * W3;
+        if (g.s_vec) {
+            const f4u v = *reinterpret_cast<const f4u*>(p + g.sc);
+            r = make_float4(v.x, v.y, v.z, v.w);
+        } else if (g.s_on) {                                // the lanes at the row's ends
+            if (g.sc >= 0 && g.sc < W3) r.x = p[g.sc];
+            if (g.sc + 1 >= 0 && g.sc + 1 < W3) r.y = p[g.sc + 1];
+            if (g.sc + 2 >= 0 && g.sc + 2 < W3) r.z = p[g.sc + 2];
+            if (g.sc + 3 >= 0 && g.sc + 3 < W3) r.w = p[g.sc + 3];
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // ordering only: LDS serves a wave's accesses in order
+    __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ float rcp_newton(float x) {
@@ -323,145 +346,184 @@ __device__ __forceinline__ float rcp_newton(float x) {
     return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.f), r);
 }
 
-__device__ __forceinline__ float4 blur_row(const float4* __restrict__ row, int t) {
-    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float4 tap = row[t + 3 * k];
-        const float w = GW[k];
-        h.x = __builtin_fmaf(w, tap.x, h.x); h.y = __builtin_fmaf(w, tap.y, h.y);
-        h.z = __builtin_fmaf(w, tap.z, h.z); h.w = __builtin_fmaf(w, tap.w, h.w);
-    }
-    return h;
+__device__ __forceinline__ void fma4(float4& a, float w, const float4& x) {
+    a.x = __builtin_fmaf(w, x.x, a.x); a.y = __builtin_fmaf(w, x.y, a.y); a.z = __builtin_fmaf(w, x.z, a.z); a.w = __builtin_fmaf(w, x.w, a.w);
 }
 
-__global__ __launch_bounds__(SCOLS) void loss_fwd_stream_kernel(int H, int W3, int R, const float* __restrict__ img1,
-                                                                 const float* __restrict__ img2, float* __restrict__ dm_dmu1,
-                                                                 float* __restrict__ dm_dsig1, float* __restrict__ dm_dsig12,
-                                                                 float* __restrict__ sums) {
-    __shared__ float4 rowbuf[2][SROW];
-    __shared__ float red[SCOLS / 64];
+__global__ __launch_bounds__(64) void loss_fwd_wave_kernel(int H, int W3, int R, const float* __restrict__ img1,
+                                                           const float* __restrict__ img2, float* __restrict__ dm_dmu1,
+                                                           float* __restrict__ dm_dsig1, float* __restrict__ dm_dsig12,
+                                                           float* __restrict__ sums) {
+    __shared__ float4 rowbuf[2][WROW];
     const size_t base = (size_t)blockIdx.z * H * W3;
     const float* a1 = img1 + base;
     const float* a2 = img2 + base;
-    const StripGeom g = strip_geom(H, W3, R);
-    const int t = threadIdx.x;
-    float4 acc[11];
+    const WaveStrip g = wave_strip(H, W3, R);
+    float4 acc[11][WO];
+#pragma unroll
+    for (int j = 0; j < 11; j++)
+#pragma unroll
+        for (int o = 0; o < WO; o++) acc[j][o] = make_float4(0.f, 0.f, 0.f, 0.f);
     float l1 = 0.f, ss = 0.f;
-    float u = strip_load(a1, g, H, W3, 0, g.cs, g.ok_s), v = strip_load(a2, g, H, W3, 0, g.cs, g.ok_s);
-    float uh = strip_load(a1, g, H, W3, 0, g.chalo, g.ok_h), vh = strip_load(a2, g, H, W3, 0, g.chalo, g.ok_h);
-    for (int ib = 0; ib < g.n_in; ib += 11) {
-#pragma unroll
-        for (int r = 0; r < 11; r++) {
-            const int i = ib + r;
-            if (i < g.n_in) {
+    float4 u4 = strip_load4(a1, g, H, W3, 0), v4 = strip_load4(a2, g, H, W3, 0);
+    for (int i = 0; i < g.n_in; i++) {
+        {
+            {
             float4* row = rowbuf[i & 1];
-            row[t] = make_float4(u, v, __builtin_fmaf(u, u, v * v), u * v);
-            if (t < 2 * SHALO) row[SCOLS + t] = make_float4(uh, vh, __builtin_fmaf(uh, uh, vh * vh), uh * vh);
+            if (g.s_on) {
+                row[4 * g.lane + 0] = make_float4(u4.x, v4.x, __builtin_fmaf(u4.x, u4.x, v4.x * v4.x), u4.x * v4.x);
+                row[4 * g.lane + 1] = make_float4(u4.y, v4.y, __builtin_fmaf(u4.y, u4.y, v4.y * v4.y), u4.y * v4.y);
+                row[4 * g.lane + 2] = make_float4(u4.z, v4.z, __builtin_fmaf(u4.z, u4.z, v4.z * v4.z), u4.z * v4.z);
+                row[4 * g.lane + 3] = make_float4(u4.w, v4.w, __builtin_fmaf(u4.w, u4.w, v4.w * v4.w), u4.w * v4.w);
+            }
             // the next row's values travel while this one is blurred
-            u = strip_load(a1, g, H, W3, i + 1, g.cs, g.ok_s); v = strip_load(a2, g, H, W3, i + 1, g.cs, g.ok_s);
-            uh = strip_load(a1, g, H, W3, i + 1, g.chalo, g.ok_h); vh = strip_load(a2, g, H, W3, i + 1, g.chalo, g.ok_h);
-            __syncthreads();
-            const float4 h = blur_row(row, t);
-            const int oc = i - HALO;                           // the output row this input row is the centre of
-            if (oc >= 0 && oc < g.n_out && g.ok_o) {
-                const float4 ctr = row[t + SHALO];
-                l1 += fabsf(ctr.x - ctr.y);
-            }
+            u4 = strip_load4(a1, g, H, W3, i + 1);
+            v4 = strip_load4(a2, g, H, W3, i + 1);
+            wave_lds_handoff();
+            float4 h[WO];
 #pragma unroll
-            for (int d = 0; d < 11; d++) {
-                float4& A = acc[(r - d + 11) % 11];
-                const float w = GW[d];
-                if (d == 0) A = make_float4(w * h.x, w * h.y, w * h.z, w * h.w);      // a new output row starts
-                else { A.x = __builtin_fmaf(w, h.x, A.x); A.y = __builtin_fmaf(w, h.y, A.y); A.z = __builtin_fmaf(w, h.z, A.z); A.w = __builtin_fmaf(w, h.w, A.w); }
+            for (int o = 0; o < WO; o++) h[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int oc = i - HALO;                           // the output row this input row is the centre of
+            const bool l1_row = oc >= 0 && oc < g.n_out;
+#pragma unroll
+            for (int m = 0; m < 10 + WO; m++) {
+                const float4 tap = row[g.ob + 3 * m];
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    const int k = m - o;
+                    if (k >= 0 && k < 11) fma4(h[o], GW[k], tap);
+                    if (k == HALO && l1_row && g.o_on[o]) l1 += fabsf(tap.x - tap.y);
+                }
             }
-            const int o = i - 2 * HALO;                        // the output row that just got its last tap
-            if (o >= 0 && g.ok_o) {
-                const float4 A4 = acc[(r + 1) % 11];
-                const float mu1 = A4.x, mu2 = A4.y;
-                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float sg_sum = (A4.z - mu1s) - mu2s, sg12 = A4.w - mu12;      // sigma1^2 + sigma2^2, sigma12
-                const float A = mu1s + mu2s + C1, B = sg_sum + C2, Cc = 2.f * mu12 + C1, D = 2.f * sg12 + C2;
-                // two reciprocals (hardware estimate + one Newton step: within an ulp of the quotient) instead of the four IEEE
-                // division sequences of the formulas as written -- 16 of the ~250 instructions of a row were v_div_*
-                const float rA = rcp_newton(A), rB = rcp_newton(B);
-                const float rAB = rA * rB;
-                ss += Cc * D * rAB;
-                const size_t p = base + (size_t)(blockIdx.y * R + o) * W3 + g.c;
-                dm_dmu1[p] = 2.f * rAB * (mu2 * (D - Cc) + mu1 * Cc * D * (rB - rA));
-                dm_dsig1[p] = -Cc * D * rAB * rB;
-                dm_dsig12[p] = 2.f * Cc * rAB;
+            wave_lds_handoff();                                // the next row's stores stay behind these reads
+            // acc[j]: the output row j rows above this input row, taps 0..j in.  An FMA writes where it likes, so the shift
+            // acc[j] = acc[j - 1] + G[j] h costs nothing, every index is static and the loop body exists once.
+#pragma unroll
+            for (int j = 10; j >= 0; j--) {
+                const float w = GW[j];
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    if (j == 0) acc[0][o] = make_float4(w * h[o].x, w * h[o].y, w * h[o].z, w * h[o].w);      // a new output row starts
+                    else acc[j][o] = make_float4(__builtin_fmaf(w, h[o].x, acc[j - 1][o].x), __builtin_fmaf(w, h[o].y, acc[j - 1][o].y),
+                                                 __builtin_fmaf(w, h[o].z, acc[j - 1][o].z), __builtin_fmaf(w, h[o].w, acc[j - 1][o].w));
+                }
+            }
+            const int orow = i - 2 * HALO;                     // the output row that just got its last tap
+            if (orow >= 0) {
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    if (!g.o_on[o]) continue;
+                    const float4 A4 = acc[10][o];
+                    const float mu1 = A4.x, mu2 = A4.y;
+                    const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+                    const float sg_sum = (A4.z - mu1s) - mu2s, sg12 = A4.w - mu12;      // sigma1^2 + sigma2^2, sigma12
+                    const float A = mu1s + mu2s + C1, B = sg_sum + C2, Cc = 2.f * mu12 + C1, D = 2.f * sg12 + C2;
+                    // two reciprocals (hardware estimate + one Newton step: within an ulp of the quotient) instead of the four
+                    // IEEE division sequences of the formulas as written
+                    const float rA = rcp_newton(A), rB = rcp_newton(B);
+                    const float rAB = rA * rB;
+                    ss += Cc * D * rAB;
+                    const size_t p = base + (size_t)(blockIdx.y * R + orow) * W3 + (g.c0 + g.ob + 3 * o);
+                    dm_dmu1[p] = 2.f * rAB * (mu2 * (D - Cc) + mu1 * Cc * D * (rB - rA));
+                    dm_dsig1[p] = -Cc * D * rAB * rB;
+                    dm_dsig12[p] = 2.f * Cc * rAB;
+                }
             }
             }
         }
     }
     l1 = wave_sum_all(l1);
     ss = wave_sum_all(ss);
-    if (lane_id() == 0) { red[t >> 6] = l1; }
-    __syncthreads();
-    if (t == 0) atomicAdd(&sums[0], red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-    if (lane_id() == 0) { red[t >> 6] = ss; }
-    __syncthreads();
-    if (t == 0) atomicAdd(&sums[1], red[0] + red[1] + red[2] + red[3]);
+    if (g.lane == 0) {
+        atomicAdd(&sums[0], l1);
+        atomicAdd(&sums[1], ss);
+    }
 }
 
 // backward: v_img1 = w_l1*sign(a-b) + w_ssim*(conv(dmu1) + 2a*conv(dsig1) + b*conv(dsig12)), the three maps blurred the same way
-__global__ __launch_bounds__(SCOLS) void loss_bwd_stream_kernel(int H, int W3, int R, const float* __restrict__ img1,
-                                                                 const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
-                                                                 const float* __restrict__ dm_dsig1, const float* __restrict__ dm_dsig12,
-                                                                 float w_l1, float w_ssim, float* __restrict__ v_img1) {
-    __shared__ float4 rowbuf[2][SROW];
+__global__ __launch_bounds__(64) void loss_bwd_wave_kernel(int H, int W3, int R, const float* __restrict__ img1,
+                                                           const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
+                                                           const float* __restrict__ dm_dsig1, const float* __restrict__ dm_dsig12,
+                                                           float w_l1, float w_ssim, float* __restrict__ v_img1) {
+    __shared__ float4 rowbuf[2][WROW];
     const size_t base = (size_t)blockIdx.z * H * W3;
     const float* m1 = dm_dmu1 + base;
     const float* m2 = dm_dsig1 + base;
     const float* m3 = dm_dsig12 + base;
-    const StripGeom g = strip_geom(H, W3, R);
-    const int t = threadIdx.x;
-    float4 acc[11];
-    float x1 = strip_load(m1, g, H, W3, 0, g.cs, g.ok_s), x2 = strip_load(m2, g, H, W3, 0, g.cs, g.ok_s), x3 = strip_load(m3, g, H, W3, 0, g.cs, g.ok_s);
-    float h1 = strip_load(m1, g, H, W3, 0, g.chalo, g.ok_h), h2 = strip_load(m2, g, H, W3, 0, g.chalo, g.ok_h), h3 = strip_load(m3, g, H, W3, 0, g.chalo, g.ok_h);
-    for (int ib = 0; ib < g.n_in; ib += 11) {
+    const WaveStrip g = wave_strip(H, W3, R);
+    float4 acc[11][WO];           // (.w unused)
 #pragma unroll
-        for (int r = 0; r < 11; r++) {
-            const int i = ib + r;
-            if (i < g.n_in) {
+    for (int j = 0; j < 11; j++)
+#pragma unroll
+        for (int o = 0; o < WO; o++) acc[j][o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 x1 = strip_load4(m1, g, H, W3, 0), x2 = strip_load4(m2, g, H, W3, 0), x3 = strip_load4(m3, g, H, W3, 0);
+    for (int i = 0; i < g.n_in; i++) {
+        {
+            {
             float4* row = rowbuf[i & 1];
-            row[t] = make_float4(x1, x2, x3, 0.f);
-            if (t < 2 * SHALO) row[SCOLS + t] = make_float4(h1, h2, h3, 0.f);
-            x1 = strip_load(m1, g, H, W3, i + 1, g.cs, g.ok_s); x2 = strip_load(m2, g, H, W3, i + 1, g.cs, g.ok_s); x3 = strip_load(m3, g, H, W3, i + 1, g.cs, g.ok_s);
-            h1 = strip_load(m1, g, H, W3, i + 1, g.chalo, g.ok_h); h2 = strip_load(m2, g, H, W3, i + 1, g.chalo, g.ok_h); h3 = strip_load(m3, g, H, W3, i + 1, g.chalo, g.ok_h);
-            // the two image values of the output row this iteration finishes
-            const int o = i - 2 * HALO;
-            float a = 0.f, b = 0.f;
-            const size_t p = base + (size_t)(blockIdx.y * R + (o >= 0 ? o : 0)) * W3 + (g.ok_o ? g.c : 0);
-            if (o >= 0) { a = img1[p]; b = img2[p]; }
-            __syncthreads();
-            const float4 h = blur_row(row, t);
-#pragma unroll
-            for (int d = 0; d < 11; d++) {
-                float4& A = acc[(r - d + 11) % 11];
-                const float w = GW[d];
-                if (d == 0) A = make_float4(w * h.x, w * h.y, w * h.z, 0.f);
-                else { A.x = __builtin_fmaf(w, h.x, A.x); A.y = __builtin_fmaf(w, h.y, A.y); A.z = __builtin_fmaf(w, h.z, A.z); }
+            if (g.s_on) {
+                row[4 * g.lane + 0] = make_float4(x1.x, x2.x, x3.x, 0.f);
+                row[4 * g.lane + 1] = make_float4(x1.y, x2.y, x3.y, 0.f);
+                row[4 * g.lane + 2] = make_float4(x1.z, x2.z, x3.z, 0.f);
+                row[4 * g.lane + 3] = make_float4(x1.w, x2.w, x3.w, 0.f);
             }
-            if (o >= 0 && g.ok_o) {
-                const float4 A4 = acc[(r + 1) % 11];
-                const float dd = a - b;
-                const float sgn = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
-                v_img1[p] = w_l1 * sgn + w_ssim * (A4.x + 2.f * a * A4.y + b * A4.z);
+            x1 = strip_load4(m1, g, H, W3, i + 1);
+            x2 = strip_load4(m2, g, H, W3, i + 1);
+            x3 = strip_load4(m3, g, H, W3, i + 1);
+            // the two image values of the output row this iteration finishes
+            const int orow = i - 2 * HALO;
+            float a[WO], b[WO];
+            size_t p[WO];
+#pragma unroll
+            for (int o = 0; o < WO; o++) {
+                p[o] = base + (size_t)(blockIdx.y * R + (orow >= 0 ? orow : 0)) * W3 + (g.o_on[o] ? g.c0 + g.ob + 3 * o : 0);
+                a[o] = 0.f; b[o] = 0.f;
+                if (orow >= 0) { a[o] = img1[p[o]]; b[o] = img2[p[o]]; }
+            }
+            wave_lds_handoff();
+            float4 h[WO];         // (.w unused)
+#pragma unroll
+            for (int o = 0; o < WO; o++) h[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < 10 + WO; m++) {
+                const float4 tap = row[g.ob + 3 * m];
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    const int k = m - o;
+                    if (k >= 0 && k < 11) fma4(h[o], GW[k], tap);
+                }
+            }
+            wave_lds_handoff();
+#pragma unroll
+            for (int j = 10; j >= 0; j--) {
+                const float w = GW[j];
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    if (j == 0) acc[0][o] = make_float4(w * h[o].x, w * h[o].y, w * h[o].z, 0.f);
+                    else acc[j][o] = make_float4(__builtin_fmaf(w, h[o].x, acc[j - 1][o].x), __builtin_fmaf(w, h[o].y, acc[j - 1][o].y),
+                                                 __builtin_fmaf(w, h[o].z, acc[j - 1][o].z), 0.f);
+                }
+            }
+            if (orow >= 0) {
+#pragma unroll
+                for (int o = 0; o < WO; o++) {
+                    if (!g.o_on[o]) continue;
+                    const float A0 = acc[10][o].x, A1 = acc[10][o].y, A2 = acc[10][o].z;
+                    const float dd = a[o] - b[o];
+                    const float sgn = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+                    v_img1[p[o]] = w_l1 * sgn + w_ssim * (A0 + 2.f * a[o] * A1 + b[o] * A2);
+                }
             }
             }
         }
     }
 }
 
-// rows per strip: enough blocks for every SIMD (256 CUs x 4) to hold about one and a half waves, at most 64 rows (10 extra rows
-// are blurred horizontally per strip), at least 16
+// rows per strip: about 1 800 waves (256 CUs x 4 SIMDs, not quite two each), at most 64 rows, at least 16 (10 extra rows are
+// blurred horizontally per strip, at about half the cost of a full row)
 static int strip_rows(int C, int H, int W3) {
-    const long long waves_per_row = (long long)C * mi_div_up(W3, SCOLS) * (SCOLS / 64);
-    long long R = (long long)H * waves_per_row / 1536;
-    R = (R + 7) / 8 * 8;
+    const long long waves_per_row = (long long)C * mi_div_up(W3, WCOLS);
+    long long R = mi_div_up((long long)H * waves_per_row, 1800ll);
     return (int)(R < 16 ? 16 : R > 64 ? 64 : R);
 }
 
@@ -481,8 +543,8 @@ extern "C" int mi3dgs_loss_fwd(int C, int height, int width, const float* render
     if (loss_stream()) {
         MI_REQUIRE((long long)height * width * 3 < (1ll << 31), "loss_fwd: image too large for 32-bit offsets");
         const int W3 = width * 3, R = strip_rows(C, height, W3);
-        dim3 grid(mi_div_up(W3, SCOLS), mi_div_up(height, R), C);
-        MI_LAUNCH("loss_fwd", loss_fwd_stream_kernel, grid, dim3(SCOLS), 0, (hipStream_t)stream, height, W3, R, render, target, dm_dmu1,
+        dim3 grid(mi_div_up(W3, WCOLS), mi_div_up(height, R), C);
+        MI_LAUNCH("loss_fwd", loss_fwd_wave_kernel, grid, dim3(64), 0, (hipStream_t)stream, height, W3, R, render, target, dm_dmu1,
                   dm_dsigma1, dm_dsigma12, sums);
         MI_LAUNCH_CHECK();
         return 0;
@@ -507,8 +569,8 @@ extern "C" int mi3dgs_loss_bwd(int C, int height, int width, const float* render
     if (loss_stream()) {
         MI_REQUIRE((long long)height * width * 3 < (1ll << 31), "loss_bwd: image too large for 32-bit offsets");
         const int W3 = width * 3, R = strip_rows(C, height, W3);
-        dim3 grid(mi_div_up(W3, SCOLS), mi_div_up(height, R), C);
-        MI_LAUNCH("loss_bwd", loss_bwd_stream_kernel, grid, dim3(SCOLS), 0, (hipStream_t)stream, height, W3, R, render, target, dm_dmu1,
+        dim3 grid(mi_div_up(W3, WCOLS), mi_div_up(height, R), C);
+        MI_LAUNCH("loss_bwd", loss_bwd_wave_kernel, grid, dim3(64), 0, (hipStream_t)stream, height, W3, R, render, target, dm_dmu1,
                   dm_dsigma1, dm_dsigma12, w_l1, w_ssim, v_render);
         MI_LAUNCH_CHECK();
         return 0;
