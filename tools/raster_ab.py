@@ -129,7 +129,30 @@ def main():
         res.append(dict(lib=path, mode=(a.modes[i] if a.modes else 1), seg_items=res_items, bwd_us_median=sorted(tb[i])[len(tb[i]) // 2], bwd_us_min=min(tb[i]),
                         fwd_us_median=sorted(tf[i])[len(tf[i]) // 2], rel_diff_vs_first=err,
                         fwd_equal_first=bool(torch.equal(fo[i][0], fo[0][0]) and torch.equal(fo[i][2], fo[0][2]))))
-    print(json.dumps(dict(scene=a.scene, absgrad=a.absgrad, n_isect=int(b["n_isect"].item()), results=res), indent=1), flush=True)
+    probe = None
+    for i, h in enumerate(handles):          # a probe build among the libraries: duration of every tile's own block against its list length
+        if not hasattr(h, "mi3dgs_debug_read_rb_stamps"):
+            continue
+        import numpy as np
+        outs[i].zero_()
+        h.mi3dgs_rasterize_bwd(*bwd_args(h, outs[i]))
+        torch.cuda.synchronize()
+        buf = np.zeros((16384, 3), dtype=np.uint64)
+        h.mi3dgs_debug_read_rb_stamps(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes))
+        nt = b["tile_width"] * b["tile_height"]
+        nw = 512 if h._seg is not None else 0
+        st = buf[nw:nw + nt].astype(np.int64)
+        ok = (st[:, 1] > 0) & (st[:, 2] > 0)
+        dur, ln = (st[ok, 1] - st[ok, 0]) / 100.0, st[ok, 2].astype(np.float64)
+        A = np.stack([np.ones_like(ln), ln], 1)
+        coef = np.linalg.lstsq(A, dur, rcond=None)[0]
+        t0 = st[st[:, 0] > 0, 0].min()
+        span = (st[ok, 1].max() - t0) / 100.0
+        probe = dict(lib=a.libs[i], blocks_with_work=int(ok.sum()), fit_us=dict(fixed=round(float(coef[0]), 2), per_1000_entries=round(float(coef[1] * 1000), 2)),
+                     duration_us=dict(median=round(float(np.median(dur)), 1), p90=round(float(np.percentile(dur, 90)), 1), max=round(float(dur.max()), 1)),
+                     walked_entries=dict(median=int(np.median(ln)), p90=int(np.percentile(ln, 90)), max=int(ln.max())), span_us=round(float(span), 1),
+                     short_blocks_median_us=round(float(np.median(dur[ln <= 64])), 1) if (ln <= 64).any() else None)
+    print(json.dumps(dict(scene=a.scene, absgrad=a.absgrad, n_isect=int(b["n_isect"].item()), results=res, probe=probe), indent=1), flush=True)
 
 
 if __name__ == "__main__":
