@@ -579,8 +579,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
 
 }  // namespace mfma_raster
 
-// Which shape: WIDE (four waves per SIMD) where many tiles of similar weight keep every CU busy, DEEP (fastest single wave)
-// where a few heavy tiles decide.  The host knows neither list lengths nor reached fractions without a sync; it knows the number
+// Which shape: WIDE (four waves per SIMD) where many blocks of similar weight keep every CU busy, DEEP (fastest single wave)
+// where a few heavy tiles decide -- which, with the segment workspace, no longer happens (see the launcher).  The host knows neither list lengths nor reached fractions without a sync; it knows the number
 // of Gaussians in the call, and the regimes measured separate on it (2 M and 300 k: WIDE wins by 13 % and 3 %; 100 k real
 // splats: DEEP wins by 2 - 6 %).  MI3DGS_BWD_WIDE_MIN moves the switch-over (documented tuning knob, include/mi3dgs.h).
 static long long bwd_wide_min() {
@@ -609,7 +609,10 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands(), n_workers, seg, render)
-    bool wide = n_gauss >= bwd_wide_min();
+    // with the segment workspace no walk is longer than 512 entries and a launch is many short blocks whose fixed cost (three
+    // dependent round trips, 11 - 16 us) is what the fourth resident block hides: WIDE then wins on the real-splat regime too
+    // (wolf 960x720 125 -> 114 us, 1920x1080 256 -> 215; 640x480 92 -> 96), profiles/r03_raster_bwd_shape_ab.txt
+    bool wide = n_gauss >= bwd_wide_min() || seg.ckpt != nullptr;
 #ifdef MI3DGS_EXPERIMENTS
     if (experiment == 21 || experiment == 22) { wide = experiment == 22; experiment = 0; }
     if (experiment == 4 && !absgrad) {           // three-term transport of the pixel sums (correct results, 24 significant bits)
