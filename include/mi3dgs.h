@@ -165,8 +165,10 @@ size_t mi3dgs_sort_workspace_bytes(long long n);
 int mi3dgs_sort_pairs_u32(uint32_t* keys, uint32_t* vals, long long n, int nbits, void* workspace,
                           size_t workspace_bytes, void* stream); /* stable, ascending, in place */
 /* A/B switch: 0 = classic radix passes (histogram + 3-kernel scan + scatter), 1 = onesweep
- * (one histogram kernel for all passes, one chained-look-back kernel per pass), 2 = onesweep
- * up to 4 M keys, classic above (the default; see binning.hip for the measurements). */
+ * (one histogram kernel for all passes, one chained-look-back kernel per pass -- or, for small
+ * sorts of at most 96 tiles (196 k keys; 786 k above the small-tile limit), ONE kernel for all passes with device-wide
+ * barriers in between), 2 = onesweep up to 4 M keys, classic above (the default; see binning.hip
+ * for the measurements), 3 = as 1 but always one launch per pass. */
 int mi3dgs_debug_set_sort_mode(int mode);
 /* A/B switch for the fused exact emit of mi3dgs_bin_tiles: 1 (default) = wave-granular (one wave = 64 depth-sorted
  * splats, no barriers), 0 = block-cooperative (round 1).  Same output bit for bit. */

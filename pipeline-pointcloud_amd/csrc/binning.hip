@@ -529,20 +529,36 @@ __device__ __forceinline__ uint32_t block_excl_scan_nw(uint32_t v, uint32_t* tot
 // look-back 4.8 us median / 6.9 max (an agent-scope load of another XCD's entry is ~0.5 us, and a tile near the end
 // needs ~10 dependent windows of 16), regroup + stores 4.4 us.  Hence 1024 threads x 8 items (8 rounds per wave, four
 // waves per SIMD) and a look-back window of OS_THREADS / 256 x OS_LB = 64 predecessors per round trip.
-template <bool DROP, int OS_THREADS, int OS_ITEMS>
-__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
+template <int OS_THREADS, int OS_ITEMS>
+struct OsShared {
+    static constexpr int NW = OS_THREADS / 64, NG = OS_THREADS / 256, OS_TILE = OS_THREADS * OS_ITEMS;
+    uint32_t cnt[NW][256];
+    uint32_t delta[256];
+    uint32_t skey[OS_TILE], sval[OS_TILE];
+    uint32_t lds_nw[NW];
+    uint32_t s_tile;
+    uint32_t lb_part[NG][256];             // look-back: the thread groups' partial sums
+};
+
+// one tile of one pass (the whole block; returns early, as a block, for a tile past the live count)
+// COH: the pairs are read and written with agent-scope accesses (sc1: past the XCD's own L2), for the one-launch sort whose
+// passes hand their output to blocks on other XCDs without a kernel boundary in between.
+template <bool DROP, int OS_THREADS, int OS_ITEMS, bool COH = false>
+__device__ __forceinline__ void os_pass_tile(
+    OsShared<OS_THREADS, OS_ITEMS>& S,
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
     const uint32_t* __restrict__ ghist_pass /*[256]*/, unsigned long long* status /*[tiles][256]*/,
     unsigned long long* gagg /*[groups][256], this pass's*/, uint32_t* tile_counter, uint32_t epoch, uint32_t* err) {
     constexpr int NW = OS_THREADS / 64, NG = OS_THREADS / 256;
     constexpr int OS_TILE = OS_THREADS * OS_ITEMS, OS_WAVE_TILE = OS_TILE / NW;
-    __shared__ uint32_t cnt[NW][256];
-    __shared__ uint32_t delta[256];
-    __shared__ uint32_t skey[OS_TILE], sval[OS_TILE];
-    __shared__ uint32_t lds_nw[NW];
-    __shared__ uint32_t s_tile;
-    __shared__ uint32_t lb_part[NG][256];             // look-back: the thread groups' partial sums
+    auto& cnt = S.cnt;
+    auto& delta = S.delta;
+    auto& skey = S.skey;
+    auto& sval = S.sval;
+    auto& lds_nw = S.lds_nw;
+    auto& s_tile = S.s_tile;
+    auto& lb_part = S.lb_part;
     uint32_t n = live_count(n_ptr, cap);
     if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
 #pragma unroll
@@ -561,8 +577,13 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
         bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+        if (COH) {
+            key[r] = valid ? __hip_atomic_load(keys_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+            val[r] = valid ? (vals_in ? __hip_atomic_load(vals_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : idx) : 0u;
+        } else {
+            key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+            val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+        }
     }
     const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
     const uint32_t my_ghist = g == 0 ? ghist_pass[d] : 0u;
@@ -670,14 +691,89 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
     for (uint32_t j = threadIdx.x; j < tot; j += OS_THREADS) {
         uint32_t k = skey[j];
         uint32_t pos = j + delta[(k >> shift) & mask];
-        keys_out[pos] = k;
-        vals_out[pos] = sval[j];
+        if (COH) {
+            __hip_atomic_store(keys_out + pos, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vals_out + pos, sval[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            keys_out[pos] = k;
+            vals_out[pos] = sval[j];
+        }
     }
     OS_STAMP(6);
 #ifdef MI3DGS_OS_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     OS_STAMP(7);
 #endif
+}
+
+
+template <bool DROP, int OS_THREADS, int OS_ITEMS>
+__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t mask,
+    const uint32_t* __restrict__ ghist_pass, unsigned long long* status, unsigned long long* gagg, uint32_t* tile_counter,
+    uint32_t epoch, uint32_t* err) {
+    __shared__ OsShared<OS_THREADS, OS_ITEMS> S;
+    os_pass_tile<DROP, OS_THREADS, OS_ITEMS>(S, keys_in, vals_in, keys_out, vals_out, n_ptr, cap, shift, mask, ghist_pass, status, gagg,
+                                             tile_counter, epoch, err);
+}
+
+// ---- all passes of a SMALL sort in one launch.  A 40 k-key depth sort (the reference's own trained scene) is five launches of
+// 8 - 10 us each in which 20 blocks do 2 us of work: launch ramp and tail, five times.  Here the blocks of one launch run the
+// passes back to back with a device-wide barrier in between.  The barrier needs every block RESIDENT at once, so the launcher only takes this path for grids that fill at most a
+// quarter of the device (two processes sharing the card can then not starve each other's blocks), and the wait is bounded like
+// every other chain's (bit 1 of the error word).
+struct OsFusedArgs {
+    uint32_t *key[2], *val[2];             // ping-pong buffers: pass p reads [p & 1], writes [(p + 1) & 1]
+    const uint32_t* n_first;               // element count of pass 0 (null: cap)
+    const uint32_t* n_later;               // element count of the later passes (the live count when sentinels are dropped)
+    uint32_t cap;
+    int passes, shift[OS_MAX_PASSES];
+    uint32_t mask[OS_MAX_PASSES];
+    const uint32_t* ghist;                 // [passes][256]
+    unsigned long long *status, *gagg;
+    size_t gagg_pass;
+    uint32_t* counters;                    // [0..3] tile counters, [4..7] barrier counters
+    uint32_t epoch_flags;
+    uint32_t* err;
+    int identity_vals;
+};
+
+__device__ __forceinline__ void os_grid_barrier(uint32_t* bar, uint32_t nblocks, uint32_t* err) {
+    // The pass's pairs were stored with agent-scope (write-through) accesses: once a wave's stores have completed they are
+    // where every XCD reads them.  So the barrier is: wait for this wave's stores, block barrier, count the block in, wait for
+    // the others.  (First version: release / acquire fences at agent scope, i.e. a write-back and an invalidate of the whole
+    // L2 per block and pass -- 60 us for a 40 k-key sort that takes 41 us as five launches.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's stores are complete
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
+            if (++spins > OS_SPIN_LIMIT) { atomicOr(err, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool DROP, int OS_THREADS, int OS_ITEMS>
+__global__ __launch_bounds__(OS_THREADS) void os_sort_fused_kernel(OsFusedArgs A) {
+    __shared__ OsShared<OS_THREADS, OS_ITEMS> S;
+    for (int p = 0; p < A.passes; p++) {
+        const uint32_t* ki = A.key[p & 1];
+        const uint32_t* vi = (p == 0 && A.identity_vals) ? nullptr : A.val[p & 1];
+        uint32_t* ko = A.key[(p + 1) & 1];
+        uint32_t* vo = A.val[(p + 1) & 1];
+        const uint32_t ep = (uint32_t)(p + 1) | A.epoch_flags;
+        if (p == 0)
+            os_pass_tile<DROP, OS_THREADS, OS_ITEMS, true>(S, ki, vi, ko, vo, A.n_first, A.cap, A.shift[0], A.mask[0], A.ghist, A.status, A.gagg,
+                                                           A.counters, ep, A.err);
+        else
+            os_pass_tile<false, OS_THREADS, OS_ITEMS, true>(S, ki, vi, ko, vo, A.n_later, A.cap, A.shift[p], A.mask[p], A.ghist + p * 256, A.status,
+                                                      A.gagg + (size_t)p * A.gagg_pass, A.counters + p, ep, A.err);
+        if (p + 1 < A.passes) os_grid_barrier(A.counters + 4 + p, gridDim.x, A.err);
+    }
 }
 
 #ifdef MI3DGS_OS_STAMPS
@@ -688,7 +784,8 @@ extern "C" int mi3dgs_debug_read_os_stamps(void* dst, size_t bytes) {
 
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 
-// 0 = classic (histogram + 3-kernel scan + scatter per pass), 1 = onesweep, 2 = by size (default).
+// 0 = classic (histogram + 3-kernel scan + scatter per pass), 1 = onesweep, 2 = by size (default), 3 = onesweep with one launch
+// per pass even where 1 and 2 would run all passes in one launch (small sorts).
 // Measured on MI355X: onesweep wins while the sort is launch-latency bound (2 M keys, 4 passes:
 // 216 -> 178 us) and loses on large sorts (15 M keys, 2 passes: 350 -> 429 us; the look-back
 // chains are dependent sc1 loads served by L2, several hundred cycles each).
@@ -789,7 +886,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
     int per = (nbits + passes - 1) / passes;
     int shift = 0;
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
-    if (g_sort_mode == 1 || (g_sort_mode == 2 && cap <= os_max_keys())) {
+    if (g_sort_mode == 1 || g_sort_mode == 3 || (g_sort_mode == 2 && cap <= os_max_keys())) {
         const uint32_t B = os_tiles_for(cap);          // (shadows the classic tile count)
         const bool small = os_items_for(cap) == OS_ITEMS_SMALL;
         // layout: ghist[4][256] | counters[8] err[1] pad[7] | status[B][256] u64
@@ -815,6 +912,37 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
             else MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         }
         static const bool wide = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
+        // small sorts: every pass in ONE launch (os_sort_fused_kernel).  Its device-wide barrier needs all B blocks resident:
+        // one 1024-thread block per CU either way (87 KB of LDS, or 76 VGPRs x 16 waves), 256 slots, and a sort takes at most 3/8 of
+        // them, so that two processes sharing the card can not hold each other's blocks out.
+        const bool half_tile = !small && os_big_items() == 16;
+        const bool fused = g_sort_mode != 3 && wide && !half_tile && passes >= 2 && B <= 96u;
+        if (fused) {
+            OsFusedArgs A;
+            A.key[0] = ki; A.key[1] = ko; A.val[0] = vi; A.val[1] = vo;
+            A.n_first = n_ptr;                                   // (null with sentinel dropping: the input size is cap)
+            A.n_later = n_live_out ? n_live_out : n_ptr;
+            A.cap = cap;
+            A.passes = passes;
+            int sh = 0;
+            for (int p = 0; p < passes; p++) {
+                const int bits = (sh + per <= nbits) ? per : (nbits - sh);
+                A.shift[p] = sh; A.mask[p] = (1u << bits) - 1u;
+                sh += bits;
+            }
+            A.ghist = ghist; A.status = status; A.gagg = gagg; A.gagg_pass = gagg_pass; A.counters = counters;
+            A.epoch_flags = os_nolookback();
+            A.err = err;
+            A.identity_vals = identity_vals ? 1 : 0;
+            const bool drop = n_live_out != nullptr;
+            if (drop) { if (small) MI_LAUNCH(ctag, (os_sort_fused_kernel<true, 1024, OS_ITEMS_SMALL / 4>), dim3(B), dim3(1024), 0, st, A);
+                        else MI_LAUNCH(ctag, (os_sort_fused_kernel<true, 1024, OS_ITEMS_BIG / 4>), dim3(B), dim3(1024), 0, st, A); }
+            else { if (small) MI_LAUNCH(ctag, (os_sort_fused_kernel<false, 1024, OS_ITEMS_SMALL / 4>), dim3(B), dim3(1024), 0, st, A);
+                   else MI_LAUNCH(ctag, (os_sort_fused_kernel<false, 1024, OS_ITEMS_BIG / 4>), dim3(B), dim3(1024), 0, st, A); }
+            MI_LAUNCH_CHECK();
+            *result_in_b = passes & 1;
+            return 0;
+        }
         for (int p = 0; p < passes; p++) {
             int bits = (shift + per <= nbits) ? per : (nbits - shift);
             uint32_t mask = (1u << bits) - 1u;
@@ -1861,7 +1989,7 @@ extern "C" int mi3dgs_bin_tiles(int C, int N, const int32_t* radii, const float*
     // 16-bit tile keys: the caller does not want the sorted keys back (its tile_keys buffer is scratch), every tile id fits, and the sort is a classic one (the 16-bit kernels exist for that path only)
     static const bool k16_on = [] { const char* e = getenv("MI3DGS_KEYS16"); return !(e && e[0] == '0'); }();
     const bool k16 = k16_on && keys_scratch && wave_emit && !isect_ids_opt && n_tiles_total <= 65536u && cap >= 64u &&
-                     !(g_sort_mode == 1 || (g_sort_mode == 2 && cap <= os_max_keys()));
+                     !(g_sort_mode == 1 || g_sort_mode == 3 || (g_sort_mode == 2 && cap <= os_max_keys()));
     uint16_t* tk16 = (uint16_t*)tile_keys;
 #define WE_LAUNCH(SPW_, KT_, TK_) MI_LAUNCH("tile_emit", (tile_emit_wave_kernel<SPW_, KT_>), dim3(mi_div_up(CN, SPW_ * WE_WAVES)), dim3(64 * WE_WAVES), 0, st, \
         CN, n_live, rir, (uint32_t)N, sorted_ids, radii, splats, tile_size, tile_width, tile_height, height, cap, TK_, fi, status, counter, err, \
@@ -1957,6 +2085,6 @@ extern "C" int mi3dgs_debug_set_emit_mode(int mode) {
 }
 
 extern "C" int mi3dgs_debug_set_sort_mode(int mode) {
-    g_sort_mode = (mode < 0 || mode > 2) ? 2 : mode;
+    g_sort_mode = (mode < 0 || mode > 3) ? 2 : mode;
     return 0;
 }
