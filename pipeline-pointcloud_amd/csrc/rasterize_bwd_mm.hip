@@ -544,10 +544,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 // The first `n_workers` blocks loop over the forward's work list (they are resident from the start of the launch and run beside
 // the tiles' own blocks; behind them they were a tail: measured 425 -> 462 us on S2 with 577 items); the blocks behind them
 // take one tile each.  Idle workers cost ~7 ns each.
-#ifndef MI_SEG_WORKERS
-#define MI_SEG_WORKERS 512
-#endif
-constexpr int SEG_WORKERS = MI_SEG_WORKERS;
+constexpr int SEG_WORKERS = 512;      // (1 024 measured the same, profiles/r03_raster_bwd_segments_ab.txt)
 
 template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
