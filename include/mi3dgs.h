@@ -195,14 +195,14 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
                          void* seg_workspace /* nullable */, size_t seg_workspace_bytes,
                          void* stream);
 /* Segment workspace (optional, training only).  One block walks a tile's list serially in the backward, so a launch is as
- * long as its heaviest tile.  Given this workspace the forward leaves its per-pixel state (T, r, g, b) at every segment
- * boundary a tile's block walks past (segments of 256 entries; 512 where the capacity exceeds 1 024 entries per tile, i.e.
- * where lists are long everywhere and balance is not the problem), and the backward -- given the SAME workspace and the
- * forward's `render` -- processes the entries in front of each boundary as work items of their own (512 extra blocks looping
- * over the list, resident from the start of the launch) while the tile's block keeps the rest.  Same gradients up to f32
- * rounding of (final colour - checkpoint colour), ~1e-5 relative.  Nothing is left for tiles that stop before their first
- * boundary.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per possible boundary
- * (max_isect / 256 of them), touched only where boundaries exist. */
+ * long as its heaviest tile.  Given this workspace the forward leaves its per-pixel state (T, r, g, b) at every 256-entry
+ * boundary a tile's block walks past, and the backward -- given the SAME workspace and the forward's `render` -- processes the
+ * entries in front of each boundary as work items of their own (512 extra blocks looping over the list, resident from the
+ * start of the launch) while the tile's block keeps the rest.  Same gradients up to f32 rounding of (final colour -
+ * checkpoint colour), ~1e-5 relative.  Nothing is left for tiles that stop before their first boundary.  Where the capacity
+ * exceeds 1 024 entries per tile (lists long everywhere: nothing to balance, and every item has a fixed cost) both calls
+ * ignore the workspace.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per
+ * possible boundary (max_isect / 256 of them), touched only where boundaries exist. */
 size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect);
 /* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it.
  * Numerics: log2 alpha of a (pixel, splat) pair is evaluated by the forward's own instruction sequence (three-term bf16

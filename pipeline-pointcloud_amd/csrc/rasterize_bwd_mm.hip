@@ -599,6 +599,7 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     if (seg_ws) {
         MI_REQUIRE(render != nullptr, "rasterize_bwd: the segment workspace needs the forward's render too");
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_bwd: segment workspace too small");
+        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};      // as the forward decided
     }
     const int n_workers = seg.ckpt ? SEG_WORKERS : 0;
     const int grid = raster_grid(n_tiles, tile_width) + n_workers;

@@ -253,10 +253,11 @@ struct PixelBasis { float u, v, uu, uv, vv; };
 // counter), and the backward processes the entries in front of each boundary as a tile of their own: transmittance from the
 // checkpoint, "colour behind" = (final colour - checkpoint colour) . v_rgb.  The tile's own block keeps the entries behind its
 // last boundary.  Tiles that stop before the first boundary leave nothing and cost one branch per batch.
-// Segment length: 256 or 512 entries, the FORWARD's choice (the backward reads it from the work items).  Shorter segments
-// balance better (S1 146 -> 118 us, wolf 1280 x 720 199 -> 153) but every item has a fixed cost, which shows where lists are long
-// and evenly long, i.e. where nothing needed balancing (S2: 577 items at 512 are free, 2 373 items at 256 cost 20 us).  The
-// capacity per tile is the host-side proxy for that: above 1 024 entries per tile the forward uses 512.
+// Segment length: 256 entries (the forward's batch).  Shorter segments balance better (S1 146 -> 118 us, wolf 1280 x 720
+// 199 -> 153 at 256 against 143 / 174 at 512), but every item has a fixed cost, which shows where lists are long and evenly long,
+// i.e. where nothing needed balancing: S2 pays 20 us for 2 373 items at 256, and even its 577 items at 512 only cost (forward
+// +4 us, backward +4 us).  The capacity per tile is the host-side proxy for that regime: above 1 024 entries per tile both
+// rasterisers ignore the workspace (seg_ws_layout returns false) and run as if none had been given.
 constexpr int SEG_MIN = 256;              // = BLOCK: the forward can only stop at its batch boundaries
 struct SegWs {
     uint32_t* ctl;        // [0] work items handed out
@@ -270,6 +271,14 @@ inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
     const size_t cap = (size_t)(max_isect / SEG_MIN) + 16;       // a boundary has >= SEG_MIN entries of its tile in front of it
     return 512 + (((size_t)n_tiles * 4 + 255) & ~(size_t)255) + cap * (16 + BLOCK * 16);
 }
+// capacity per tile above which the workspace is not used (lists long everywhere: nothing to balance)
+constexpr size_t SEG_OFF_ENTRIES_PER_TILE = 1024;
+inline bool seg_ws_in_use(int n_tiles, size_t bytes) {
+    const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255, fixed = 512 + nb_bytes;
+    if (bytes < fixed + (16 + BLOCK * 16)) return false;
+    const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
+    return (cap > 16 ? cap - 16 : 0) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) <= SEG_OFF_ENTRIES_PER_TILE;
+}
 // both rasterisers derive the same views from (n_tiles, bytes)
 inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {
     const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255;
@@ -282,7 +291,7 @@ inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {
     out->work = (uint4*)(b + 256 + nb_bytes);
     out->ckpt = (float4*)(b + 256 + nb_bytes + ((cap * 16 + 255) & ~(size_t)255));
     out->cap = (uint32_t)cap;
-    out->seg = ((cap - 16) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) > 1024) ? 512u : 256u;
+    out->seg = SEG_MIN;
     return true;
 }
 

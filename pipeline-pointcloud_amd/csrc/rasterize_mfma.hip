@@ -347,7 +347,8 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
     SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (seg_ws) {
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_fwd: segment workspace too small (mi3dgs_raster_seg_workspace_bytes)");
-        MI_HIP(hipMemsetAsync(seg.ctl, 0, 64, st));
+        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+        else MI_HIP(hipMemsetAsync(seg.ctl, 0, 64, st));
     }
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
