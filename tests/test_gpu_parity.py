@@ -31,7 +31,7 @@ def test_scan_exclusive_bit_exact(dev, n):
 
 @pytest.mark.parametrize("mode", [0, 1, 3])       # classic multi-kernel passes / onesweep (all passes in one launch up to 96 tiles) / onesweep, one launch per pass
 @pytest.mark.parametrize("n,nbits", [(1, 32), (64, 32), (4096, 32), (5000, 13), (100_003, 32), (196_608, 32), (196_609, 32),
-                                     (600_000, 16), (1_500_000, 13), (300_000, 7)])
+                                     (600_000, 16), (900_000, 32), (1_500_000, 13), (1_600_000, 13), (300_000, 7)])
 def test_radix_sort_stable_bit_exact(dev, n, nbits, mode):
     ops = _ops()
     ops._lib.lib().mi3dgs_debug_set_sort_mode(mode)
