@@ -222,7 +222,9 @@ def raster_seg_workspace(binning, Cn, device, out=None):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         if out is not None:
             out["seg_ws"] = ws
-    return ws
+    # exactly the size of THIS call's lists: both rasterisers derive the layout (and whether lists are long enough everywhere
+    # for segments to be pointless) from the byte count
+    return ws[:nbytes]
 
 
 def rasterize_fwd(splats, binning, width, height, tile_size=16, backgrounds=None, out=None, seg_ws=None):
