@@ -559,7 +559,7 @@ __device__ __forceinline__ void os_pass_tile(
     auto& lds_nw = S.lds_nw;
     auto& s_tile = S.s_tile;
     auto& lb_part = S.lb_part;
-    uint32_t n = live_count(n_ptr, cap);
+    uint32_t n = COH && n_ptr ? min(__hip_atomic_load(n_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cap) : live_count(n_ptr, cap);
     if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
 #pragma unroll
     for (int i = 0; i < NW * 256 / OS_THREADS; i++) (&cnt[0][0])[i * OS_THREADS + threadIdx.x] = 0;
@@ -586,7 +586,8 @@ __device__ __forceinline__ void os_pass_tile(
         }
     }
     const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
-    const uint32_t my_ghist = g == 0 ? ghist_pass[d] : 0u;
+    // (COH: the histograms were built by atomics of this same launch)
+    const uint32_t my_ghist = g == 0 ? (COH ? __hip_atomic_load(ghist_pass + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ghist_pass[d]) : 0u;
 #pragma unroll
     for (int r = 0; r < OS_ITEMS; r++) {
         uint32_t idx = wbase + r * 64 + lane;
@@ -737,6 +738,8 @@ struct OsFusedArgs {
     uint32_t epoch_flags;
     uint32_t* err;
     int identity_vals;
+    uint32_t* ghist_w;                     // the same histograms, for the in-kernel histogram phase
+    uint32_t* n_live_out;                  // DROP: receives the number of keys that are not sentinels
 };
 
 __device__ __forceinline__ void os_grid_barrier(uint32_t* bar, uint32_t nblocks, uint32_t* err) {
@@ -757,9 +760,49 @@ __device__ __forceinline__ void os_grid_barrier(uint32_t* bar, uint32_t nblocks,
     __syncthreads();
 }
 
+// the digit histograms of every pass over this block's tile (what os_hist_kernel does as a launch of its own), and the live count
+template <bool DROP, int OS_THREADS, int OS_ITEMS>
+__device__ __forceinline__ void os_hist_phase(OsShared<OS_THREADS, OS_ITEMS>& S, const OsFusedArgs& A) {
+    constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
+    static_assert(OS_THREADS / 64 >= OS_MAX_PASSES, "the per-wave counter rows double as the histogram rows");
+    const uint32_t n = live_count(A.n_first, A.cap);
+    const uint32_t base = blockIdx.x * OS_TILE;
+    for (int i = threadIdx.x; i < OS_MAX_PASSES * 256; i += OS_THREADS) (&S.cnt[0][0])[i] = 0;
+    __syncthreads();
+    if (base < n) {
+        const uint32_t* keys = A.key[0];
+        uint32_t kreg[OS_ITEMS];
+#pragma unroll
+        for (int i = 0; i < OS_ITEMS; i++) {
+            const uint32_t idx = base + i * OS_THREADS + threadIdx.x;
+            kreg[i] = idx < n ? keys[idx] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int i = 0; i < OS_ITEMS; i++) {
+            const uint32_t idx = base + i * OS_THREADS + threadIdx.x;
+            if (idx >= n || (DROP && kreg[i] == 0xFFFFFFFFu)) continue;
+            for (int p = 0; p < A.passes; p++) atomicAdd(&S.cnt[p][(kreg[i] >> A.shift[p]) & A.mask[p]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        for (int p = 0; p < A.passes; p++) {
+            const uint32_t c = S.cnt[p][threadIdx.x];
+            if (c) __hip_atomic_fetch_add(A.ghist_w + p * 256 + threadIdx.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (DROP) {                                       // the block's live keys = the sum of any one pass's counters
+            const uint32_t tot = wave_sum_all_u32(S.cnt[0][threadIdx.x]);
+            if (lane_id() == 0 && tot) __hip_atomic_fetch_add(A.n_live_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // (the first pass's prologue clears the counter rows again behind its own barrier)
+}
+
 template <bool DROP, int OS_THREADS, int OS_ITEMS>
 __global__ __launch_bounds__(OS_THREADS) void os_sort_fused_kernel(OsFusedArgs A) {
     __shared__ OsShared<OS_THREADS, OS_ITEMS> S;
+    os_hist_phase<DROP, OS_THREADS, OS_ITEMS>(S, A);
+    os_grid_barrier(A.counters + 4 + (OS_MAX_PASSES - 1), gridDim.x, A.err);
     for (int p = 0; p < A.passes; p++) {
         const uint32_t* ki = A.key[p & 1];
         const uint32_t* vi = (p == 0 && A.identity_vals) ? nullptr : A.val[p & 1];
@@ -900,9 +943,18 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
         if (!zeroed) MI_HIP(hipMemsetAsync(tmp, 0, os_ctl_u32(cap) * sizeof(uint32_t), st));
         unsigned long long* gagg = status + (size_t)256 * B;
         const size_t gagg_pass = (size_t)256 * ((B + OS_GRP - 1) / OS_GRP);
+        static const bool wide = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
+        // small sorts: the histograms and every pass in ONE launch (os_sort_fused_kernel).  Its device-wide barriers need all B blocks
+        // resident: one 1024-thread block per CU (87 KB of LDS, or 76 VGPRs x 16 waves), 256 slots, and a sort takes at most 3/8 of
+        // them, so that two processes sharing the card can not hold each other's blocks out.
+        const bool half_tile = !small && os_big_items() == 16;
+        const bool fused = g_sort_mode != 3 && wide && !half_tile && passes >= 2 && B <= 96u;
         if (n_live_out) {
             MI_REQUIRE(!n_ptr, "sort: sentinel dropping needs a host-known input size");
             if (!zeroed) MI_HIP(hipMemsetAsync(n_live_out, 0, sizeof(uint32_t), st));
+        }
+        if (fused) {
+        } else if (n_live_out) {
             if (small) MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_SMALL>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else if (os_big_items() == 16) MI_LAUNCH(htag, (os_hist_kernel<true, 16>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else MI_LAUNCH(htag, (os_hist_kernel<true, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
@@ -911,12 +963,6 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
             else if (os_big_items() == 16) MI_LAUNCH(htag, (os_hist_kernel<false, 16>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
             else MI_LAUNCH(htag, (os_hist_kernel<false, OS_ITEMS_BIG>), dim3(B), dim3(RS_THREADS), 0, st, ki, n_ptr, cap, passes, per, nbits, ghist, n_live_out);
         }
-        static const bool wide = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_OS_THREADS"); return !(e && atoi(e) == 256); }();
-        // small sorts: every pass in ONE launch (os_sort_fused_kernel).  Its device-wide barrier needs all B blocks resident:
-        // one 1024-thread block per CU either way (87 KB of LDS, or 76 VGPRs x 16 waves), 256 slots, and a sort takes at most 3/8 of
-        // them, so that two processes sharing the card can not hold each other's blocks out.
-        const bool half_tile = !small && os_big_items() == 16;
-        const bool fused = g_sort_mode != 3 && wide && !half_tile && passes >= 2 && B <= 96u;
         if (fused) {
             OsFusedArgs A;
             A.key[0] = ki; A.key[1] = ko; A.val[0] = vi; A.val[1] = vo;
@@ -934,6 +980,7 @@ int radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint3
             A.epoch_flags = os_nolookback();
             A.err = err;
             A.identity_vals = identity_vals ? 1 : 0;
+            A.ghist_w = ghist; A.n_live_out = n_live_out;
             const bool drop = n_live_out != nullptr;
             if (drop) { if (small) MI_LAUNCH(ctag, (os_sort_fused_kernel<true, 1024, OS_ITEMS_SMALL / 4>), dim3(B), dim3(1024), 0, st, A);
                         else MI_LAUNCH(ctag, (os_sort_fused_kernel<true, 1024, OS_ITEMS_BIG / 4>), dim3(B), dim3(1024), 0, st, A); }
