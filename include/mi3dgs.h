@@ -235,6 +235,14 @@ int mi3dgs_loss_fwd(int C, int height, int width, const float* render, const flo
 int mi3dgs_loss_bwd(int C, int height, int width, const float* render, const float* target,
                     const float* dm_dmu1, const float* dm_dsigma1, const float* dm_dsigma12,
                     float ssim_lambda, float loss_scale, float* v_render, void* stream);
+/* The same with the target straight from a uint8 image cache [C,H,W,3]: the kernels form value * scale (scale = 1 / 255)
+ * themselves -- the same product mi3dgs_image_u8_to_f32 forms, hence the same results -- and the per-step conversion launch
+ * of the nerfstudio-style cache (cache_images_type uint8) disappears. */
+int mi3dgs_loss_fwd_u8(int C, int height, int width, const float* render, const uint8_t* target_u8, float scale,
+                       float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream);
+int mi3dgs_loss_bwd_u8(int C, int height, int width, const float* render, const uint8_t* target_u8, float scale,
+                       const float* dm_dmu1, const float* dm_dsigma1, const float* dm_dsigma12,
+                       float ssim_lambda, float loss_scale, float* v_render, void* stream);
 /* splatfacto use_scale_regularization (reference main.py:1288): loss_sum[0] (nullable) +=
  * weight*mean(max(ratio,max_ratio)-max_ratio); v_scales (nullable, log-space) accumulated. */
 int mi3dgs_scale_reg(int N, const float* scales_log, float weight, float max_ratio, float* v_scales,

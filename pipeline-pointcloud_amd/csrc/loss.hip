@@ -60,6 +60,12 @@ static_assert(ROW3 <= ST_COLS && NT % ST_COLS == 0, "staging layout");
 
 struct StageCol { int j, rgrp, xj, col, ch; bool xok; };
 
+// the target image comes as float32 in [0, 1] or straight from the uint8 image cache (value * scale, scale = 1 / 255: the same
+// product mi3dgs_image_u8_to_f32 forms, so both routes give the same bits; the conversion pass it saves was a launch of its own
+// in every training step)
+__device__ __forceinline__ float px_load(const float* p, int off, float) { return p[off]; }
+__device__ __forceinline__ float px_load(const uint8_t* p, int off, float scale) { return (float)p[off] * scale; }
+
 __device__ __forceinline__ StageCol stage_col(int W, int x0) {
     StageCol c;
     c.j = (int)threadIdx.x & (ST_COLS - 1);
@@ -71,14 +77,15 @@ __device__ __forceinline__ StageCol stage_col(int W, int x0) {
     return c;
 }
 
-__device__ __forceinline__ void stage_load(const float* __restrict__ img, int H, int W, int y0, const StageCol& c,
-                                           float (&v)[ST_ITERS]) {
+template <typename PT>
+__device__ __forceinline__ void stage_load(const PT* __restrict__ img, int H, int W, int y0, const StageCol& c,
+                                           float (&v)[ST_ITERS], float scale = 1.f) {
 #pragma unroll
     for (int it = 0; it < ST_ITERS; it++) {
         const int y = y0 + it * ST_RGRP + c.rgrp - HALO;
         const bool ok = c.xok && y >= 0 && y < H;
         const int off = ok ? y * (W * 3) + c.xj : 0;      // 32-bit offset from a uniform base: saddr addressing, one VGPR
-        const float val = img[off];
+        const float val = px_load(img, off, scale);
         v[it] = ok ? val : 0.f;
     }
 }
@@ -98,8 +105,9 @@ __device__ __forceinline__ void stage_store(float (*plane)[LW][LS], const StageC
 // The first version (16x16 tiles, one output per thread, 55 LDS reads per pixel-channel in
 // the vertical pass, 2-way bank conflicts on half its LDS cycles) took 232 us; the halo
 // overhead drops from 2.6x to 1.7x and LDS reads per output from 77 to 25.
+template <typename TT>
 __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const float* __restrict__ img1,
-                                                       const float* __restrict__ img2, float* __restrict__ dm_dmu1,
+                                                       const TT* __restrict__ img2, float t_scale, float* __restrict__ dm_dmu1,
                                                        float* __restrict__ dm_dsig1, float* __restrict__ dm_dsig12,
                                                        float* __restrict__ sums /* [0]=L1 sum, [1]=SSIM sum */) {
     __shared__ float pu[3][LW][LS], pv[3][LW][LS];
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
         const StageCol sc = stage_col(W, x0);
         float ra[ST_ITERS], rb[ST_ITERS];
         stage_load(img1 + base, H, W, y0, sc, ra);
-        stage_load(img2 + base, H, W, y0, sc, rb);
+        stage_load(img2 + base, H, W, y0, sc, rb, t_scale);
         stage_store(pu, sc, ra);
         stage_store(pv, sc, rb);
     }
@@ -191,8 +199,9 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
 }
 
 // backward: v_img1 = w_l1*sign(a-b) + w_ssim*(conv(dmu1) + 2a*conv(dsig1) + b*conv(dsig12))
+template <typename TT>
 __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float* __restrict__ img1,
-                                                       const float* __restrict__ img2,
+                                                       const TT* __restrict__ img2, float t_scale,
                                                        const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dsig1,
                                                        const float* __restrict__ dm_dsig12, float w_l1, float w_ssim,
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(NT) void loss_bwd_kernel(int H, int W, const float*
             bool in = px < W && py < H;
             int off = ((in ? py : 0) * W + (in ? px : 0)) * 3 + ch;
             pu_[ch][o] = (img1 + base)[off];
-            pv_[ch][o] = (img2 + base)[off];
+            pv_[ch][o] = px_load(img2 + base, off, t_scale);
         }
 #pragma unroll
     for (int m = 0; m < 3; m++) {
@@ -551,8 +560,18 @@ extern "C" int mi3dgs_loss_fwd(int C, int height, int width, const float* render
     }
 #endif
     dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
-    MI_LAUNCH("loss_fwd", loss_fwd_kernel, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
+    MI_LAUNCH("loss_fwd", loss_fwd_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target, 1.f, dm_dmu1,
               dm_dsigma1, dm_dsigma12, sums);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_loss_fwd_u8(int C, int height, int width, const float* render, const uint8_t* target_u8, float scale,
+                                  float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream) {
+    MI_REQUIRE(C > 0 && height > 0 && width > 0, "loss_fwd_u8: bad sizes");
+    dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
+    MI_LAUNCH("loss_fwd", loss_fwd_kernel<uint8_t>, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target_u8, scale,
+              dm_dmu1, dm_dsigma1, dm_dsigma12, sums);
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -577,8 +596,22 @@ extern "C" int mi3dgs_loss_bwd(int C, int height, int width, const float* render
     }
 #endif
     dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
-    MI_LAUNCH("loss_bwd", loss_bwd_kernel, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target, dm_dmu1,
+    MI_LAUNCH("loss_bwd", loss_bwd_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target, 1.f, dm_dmu1,
               dm_dsigma1, dm_dsigma12, w_l1, w_ssim, v_render);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi3dgs_loss_bwd_u8(int C, int height, int width, const float* render, const uint8_t* target_u8, float scale,
+                                  const float* dm_dmu1, const float* dm_dsigma1, const float* dm_dsigma12, float ssim_lambda,
+                                  float loss_scale, float* v_render, void* stream) {
+    MI_REQUIRE(C > 0 && height > 0 && width > 0, "loss_bwd_u8: bad sizes");
+    float M = (float)C * (float)height * (float)width * 3.f;
+    float w_l1 = loss_scale * (1.f - ssim_lambda) / M;
+    float w_ssim = -loss_scale * ssim_lambda / M;
+    dim3 grid(mi_div_up(width, LT), mi_div_up(height, LT), C);
+    MI_LAUNCH("loss_bwd", loss_bwd_kernel<uint8_t>, grid, dim3(NT), 0, (hipStream_t)stream, height, width, render, target_u8, scale,
+              dm_dmu1, dm_dsigma1, dm_dsigma12, w_l1, w_ssim, v_render);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "mi3dgs_raster_seg_workspace_bytes": (_sz, [_i, _ll]),
     "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
+    "mi3dgs_loss_fwd_u8": (_i, [_i, _i, _i, _f, _f, _fl, _f, _f, _f, _f, _f]),
+    "mi3dgs_loss_bwd_u8": (_i, [_i, _i, _i, _f, _f, _fl, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_scale_reg": (_i, [_i, _f, _fl, _fl, _f, _f, _f]),
     "mi3dgs_adam_step": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_ll),
                               C.POINTER(_fl), _i, _fl, _fl, _fl, _fl, _f]),

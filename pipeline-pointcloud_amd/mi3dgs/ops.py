@@ -270,14 +270,19 @@ def loss_fwd(render, target, scratch=None):
     """Returns (sums[2] device tensor = {sum|r-t|, sum SSIM}, scratch dict for loss_bwd)."""
     Cn, H, W, _ = render.shape
     dev = render.device
-    _chk(render, "render", (Cn, H, W, 3)); _chk(target, "target", (Cn, H, W, 3))
+    _chk(render, "render", (Cn, H, W, 3))
+    _chk(target, "target", (Cn, H, W, 3), dtype=torch.uint8 if target.dtype == torch.uint8 else torch.float32)
     s = scratch if scratch is not None else {}
     if "dm1" not in s:
         s["dm1"] = torch.empty_like(render); s["dm2"] = torch.empty_like(render); s["dm3"] = torch.empty_like(render)
         s["sums"] = torch.zeros(2, dtype=torch.float32, device=dev)
     s["sums"].zero_()
-    _lib.call("mi3dgs_loss_fwd", Cn, H, W, _p(render), _p(target), _p(s["dm1"]), _p(s["dm2"]), _p(s["dm3"]),
-              _p(s["sums"]), _stream(dev))
+    if target.dtype == torch.uint8:         # straight from the uint8 image cache: value / 255 formed inside the kernel
+        _lib.call("mi3dgs_loss_fwd_u8", Cn, H, W, _p(render), _p(target), 1.0 / 255.0, _p(s["dm1"]), _p(s["dm2"]), _p(s["dm3"]),
+                  _p(s["sums"]), _stream(dev))
+    else:
+        _lib.call("mi3dgs_loss_fwd", Cn, H, W, _p(render), _p(target), _p(s["dm1"]), _p(s["dm2"]), _p(s["dm3"]),
+                  _p(s["sums"]), _stream(dev))
     return s["sums"], s
 
 
@@ -285,8 +290,12 @@ def loss_bwd(render, target, scratch, ssim_lambda=0.2, loss_scale=1.0, v_render=
     Cn, H, W, _ = render.shape
     if v_render is None:
         v_render = torch.empty_like(render)
-    _lib.call("mi3dgs_loss_bwd", Cn, H, W, _p(render), _p(target), _p(scratch["dm1"]), _p(scratch["dm2"]),
-              _p(scratch["dm3"]), float(ssim_lambda), float(loss_scale), _p(v_render), _stream(render.device))
+    if target.dtype == torch.uint8:
+        _lib.call("mi3dgs_loss_bwd_u8", Cn, H, W, _p(render), _p(target), 1.0 / 255.0, _p(scratch["dm1"]), _p(scratch["dm2"]),
+                  _p(scratch["dm3"]), float(ssim_lambda), float(loss_scale), _p(v_render), _stream(render.device))
+    else:
+        _lib.call("mi3dgs_loss_bwd", Cn, H, W, _p(render), _p(target), _p(scratch["dm1"]), _p(scratch["dm2"]),
+                  _p(scratch["dm3"]), float(ssim_lambda), float(loss_scale), _p(v_render), _stream(render.device))
     return v_render
 
 

@@ -151,11 +151,8 @@ class Trainer:
         dev = self.model.device
         self.device = dev
         self.viewmats, self.Ks = viewmats.to(dev).contiguous(), Ks.to(dev).contiguous()
-        # [V,H,W,3] on the device: float32 in [0,1], or the uint8 image cache (a quarter of the HBM;
-        # the step converts its one target with ops.image_u8_to_f32)
+        # [V,H,W,3] on the device: float32 in [0,1], or the uint8 image cache (a quarter of the HBM; the loss kernels read it as it is)
         self.images = images
-        self._gt_f32 = (torch.empty(1, int(height), int(width), 3, dtype=torch.float32, device=dev)
-                        if images is not None and images.dtype == torch.uint8 else None)
         self.W, self.H = int(width), int(height)
         self.W0, self.H0, self.Ks0, self._cur_d = self.W, self.H, self.Ks, 1
         self._auto_cap: Optional[int] = None       # auto_isect_capacity: current capacity, None = measure first
@@ -229,11 +226,9 @@ class Trainer:
         self.raster_out, self.loss_scratch = {}, {}
         self.v_render = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
         self.v_alphas = torch.zeros(1, self.H, self.W, 1, dtype=torch.float32, device=dev)
-        if self._gt_f32 is not None:
-            self._gt_f32 = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
 
     def _target(self, view_index: int) -> torch.Tensor:
-        """[1,H,W,3] float32 target of the current resolution level."""
+        """[1,H,W,3] target of the current resolution level: float32, or uint8 at full resolution from a uint8 cache."""
         img, d = self.images[view_index], self._cur_d
         if d > 1:
             Hc, Wc = self.H * d, self.W * d                # nerfstudio's strided box filter drops the remainder
@@ -242,9 +237,7 @@ class Trainer:
             if img.dtype == torch.uint8:
                 return ops.image_downscale_area(img, self.H, self.W, as_float=True)[None]
             return img.view(self.H, d, self.W, d, 3).mean(dim=(1, 3))[None].contiguous()
-        if self._gt_f32 is not None:
-            return ops.image_u8_to_f32(img[None], self._gt_f32)
-        return img[None]
+        return img[None]          # float32, or uint8 straight from the image cache (the loss kernels form value / 255 themselves)
 
     def sh_degree_now(self) -> int:
         return min(self.step_count // self.cfg.sh_degree_interval, self.cfg.sh_degree)

@@ -312,6 +312,24 @@ def test_loss_fwd_bwd_matches_oracle(dev, C, H, W):
     assert rel_err(v.cpu(), ad.grad) < 1e-4
 
 
+def test_loss_reads_the_uint8_image_cache_itself(dev):
+    """Same bits as converting first (mi3dgs_image_u8_to_f32, value * (1 / 255)) and calling the float32 entry points."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    C, H, W = 2, 77, 101
+    r = torch.rand(C, H, W, 3, generator=g).to(dev)
+    t8 = torch.randint(0, 256, (C, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    tf = ops.image_u8_to_f32(t8)
+    assert torch.equal(tf, t8.float() * torch.tensor(1.0 / 255.0, device=dev))
+    s_f, sc_f = ops.loss_fwd(r, tf)
+    v_f = ops.loss_bwd(r, tf, sc_f, 0.2, 1.0).clone()
+    s_f, dm_f = s_f.clone(), [sc_f[k].clone() for k in ("dm1", "dm2", "dm3")]
+    s_8, sc_8 = ops.loss_fwd(r, t8)
+    v_8 = ops.loss_bwd(r, t8, sc_8, 0.2, 1.0)
+    assert all(torch.equal(a, sc_8[k]) for a, k in zip(dm_f, ("dm1", "dm2", "dm3"))) and torch.equal(v_f, v_8)
+    assert torch.allclose(s_f, s_8, rtol=1e-6)          # (block sums meet in float atomics: order)
+
+
 # -------------------------------------------------------------------------------- Adam
 def test_adam_matches_oracle_and_torch(dev):
     ops = _ops()
