@@ -42,6 +42,10 @@ extern "C" {
 #define MI3DGS_FLAG_LOG_SCALES 1   /* scales are log-space parameters; exp() fused */
 #define MI3DGS_FLAG_LOGIT_OPAC 2   /* opacities are logits; sigmoid() fused */
 #define MI3DGS_FLAG_ANTIALIASED 4  /* rasterize_mode "antialiased": opacity *= compensation */
+#define MI3DGS_FLAG_CLEAR_VSPLATS 8 /* project_bwd / project_bwd_adam, one camera with SH colours only: the v_splats row of every
+                                      visible Gaussian is zeroed once it has been read (rasterize_bwd touches no other rows), so
+                                      that the next step's rasterize_bwd finds the buffer clear without a fill pass of its own.
+                                      The buffer is written through the `const` pointer: it must be writable. */
 
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
@@ -228,8 +232,8 @@ int mi3dgs_debug_set_raster_mode(int mode);
 
 /* ---- loss ----------------------------------------------------------------------------
  * Replaces the L1 + SSIM(11x11, sigma 1.5) loss of splatfacto / simple_trainer.
- * sums[2] (zeroed by the caller) receives {sum |r-t|, sum SSIM map}; the three dm_* maps
- * [C,H,W,3] are scratch handed from fwd to bwd. */
+ * sums[2] (zeroed by the caller; nullable when the loss VALUE of the step is not wanted) receives
+ * {sum |r-t|, sum SSIM map}; the three dm_* maps [C,H,W,3] are scratch handed from fwd to bwd. */
 int mi3dgs_loss_fwd(int C, int height, int width, const float* render, const float* target,
                     float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream);
 int mi3dgs_loss_bwd(int C, int height, int width, const float* render, const float* target,

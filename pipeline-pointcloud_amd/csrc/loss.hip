@@ -190,6 +190,7 @@ __global__ __launch_bounds__(NT, 4) void loss_fwd_kernel(int H, int W, const flo
         }
         __syncthreads();
     }
+    if (sums == nullptr) return;             // the caller does not read the loss value of this step (block-uniform)
     l1 = block_sum(l1, red);
     ss = block_sum(ss, red);
     if (threadIdx.x == 0) {
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(64) void loss_fwd_wave_kernel(int H, int W3, int R,
             }
         }
     }
+    if (sums == nullptr) return;
     l1 = wave_sum_all(l1);
     ss = wave_sum_all(ss);
     if (g.lane == 0) {
@@ -544,7 +546,8 @@ static bool loss_stream() {
 
 }  // namespace
 
-// sums[2] must be zeroed by the caller (hipMemsetAsync on the same stream) before the call.
+// sums[2] must be zeroed by the caller (hipMemsetAsync on the same stream) before the call; nullable: a training step that does
+// not report its loss value needs neither the clear nor the reduction (the gradient pass only uses the three maps).
 extern "C" int mi3dgs_loss_fwd(int C, int height, int width, const float* render, const float* target,
                                float* dm_dmu1, float* dm_dsigma1, float* dm_dsigma12, float* sums, void* stream) {
     MI_REQUIRE(C > 0 && height > 0 && width > 0, "loss_fwd: bad sizes");

@@ -593,7 +593,7 @@ template <bool FUSE>
 __global__ __launch_bounds__(256) void project_bwd1_kernel(
     int N, float* means, float* quats, float* scales, float* opacities, float* shN, int sh_degree, FusedAdam A,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int W, int H, float eps2d, int flags,
-    const int32_t* __restrict__ radii, const float* __restrict__ splats, const float* __restrict__ v_splats,
+    const int32_t* __restrict__ radii, const float* __restrict__ splats, float* v_splats /* read; cleared with MI_FLAG_CLEAR_VSPLATS */,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
     float* __restrict__ v_opacities, float* __restrict__ v_sh0, float* __restrict__ v_shN,
     float* __restrict__ stat_grad2d, float* __restrict__ stat_count, float* __restrict__ stat_radii, int stat_use_abs) {
@@ -661,8 +661,12 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
         float Sw[9];
         quat_to_rotmat(q, Rq, inv_norm);
         covar_world(Rq, s, Sw);
-        const float4* vr = reinterpret_cast<const float4*>(v_splats + (long long)n * GRAD_STRIDE);
+        float4* vr = reinterpret_cast<float4*>(v_splats + (long long)n * GRAD_STRIDE);
         float4 g0 = vr[0], g1 = vr[1], g2 = vr[2];
+        if (flags & MI_FLAG_CLEAR_VSPLATS) {        // rasterize_bwd accumulates into floats 0..10 of visible rows only
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[0] = z4; vr[1] = z4; vr[2] = z4;
+        }
         float v_rgb[3] = {g1.z, g1.w, g2.x};
         {
             float sx = stat_use_abs ? g2.y : g0.x, sy = stat_use_abs ? g2.z : g0.y;
@@ -1001,12 +1005,13 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
     if (N == 0) return 0;
     const bool fast = C == 1 && color_mode == 0 && ((((uintptr_t)shN) | ((uintptr_t)v_shN) | ((uintptr_t)quats) |
                                                      ((uintptr_t)v_quats)) & 15) == 0;
+    MI_REQUIRE(fast || !(flags & MI_FLAG_CLEAR_VSPLATS), "project_bwd: the CLEAR_VSPLATS flag needs the one-camera SH path");
     if (fast) {
         FusedAdam none = {};
         MI_LAUNCH("project_bwd", (project_bwd1_kernel<false>), dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
                   const_cast<float*>(means), const_cast<float*>(quats), const_cast<float*>(scales),
                   const_cast<float*>(opacities), const_cast<float*>(shN), sh_degree, none, viewmats, Ks, width, height,
-                  eps2d, flags, radii, splats, v_splats, v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN,
+                  eps2d, flags, radii, splats, const_cast<float*>(v_splats), v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN,
                   stat_grad2d, stat_count, stat_radii, stat_use_abs);
     }
     else
@@ -1047,7 +1052,7 @@ extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float*
     A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
     MI_LAUNCH("project_bwd_adam", (project_bwd1_kernel<true>), dim3(mi_div_up(N, 256)), dim3(256), 0,
               (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
-                  eps2d, flags, radii, splats, v_splats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,
+                  eps2d, flags, radii, splats, const_cast<float*>(v_splats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,
                   stat_count, stat_radii, stat_use_abs);
     MI_LAUNCH_CHECK();
     return 0;

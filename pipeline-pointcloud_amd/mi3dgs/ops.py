@@ -21,6 +21,7 @@ GRAD_STRIDE = 16
 FLAG_LOG_SCALES = 1
 FLAG_LOGIT_OPAC = 2
 FLAG_ANTIALIASED = 4
+FLAG_CLEAR_VSPLATS = 8      # project_bwd / project_bwd_adam: clear the v_splats rows they read (include/mi3dgs.h)
 COLOR_SH, COLOR_PER_GAUSSIAN, COLOR_PER_CAMERA = 0, 1, 2
 
 
@@ -266,8 +267,9 @@ def rasterize_bwd(splats, binning, width, height, alphas, last_ids, v_render, v_
     return v_splats
 
 
-def loss_fwd(render, target, scratch=None):
-    """Returns (sums[2] device tensor = {sum|r-t|, sum SSIM}, scratch dict for loss_bwd)."""
+def loss_fwd(render, target, scratch=None, want_sums=True):
+    """Returns (sums[2] device tensor = {sum|r-t|, sum SSIM}, scratch dict for loss_bwd).  want_sums=False: the sums are neither
+    cleared nor written (None is returned for them): a training step that does not report its loss saves the clear's launch."""
     Cn, H, W, _ = render.shape
     dev = render.device
     _chk(render, "render", (Cn, H, W, 3))
@@ -276,14 +278,16 @@ def loss_fwd(render, target, scratch=None):
     if "dm1" not in s:
         s["dm1"] = torch.empty_like(render); s["dm2"] = torch.empty_like(render); s["dm3"] = torch.empty_like(render)
         s["sums"] = torch.zeros(2, dtype=torch.float32, device=dev)
-    s["sums"].zero_()
+    sums = s["sums"] if want_sums else None
+    if want_sums:
+        sums.zero_()
     if target.dtype == torch.uint8:         # straight from the uint8 image cache: value / 255 formed inside the kernel
         _lib.call("mi3dgs_loss_fwd_u8", Cn, H, W, _p(render), _p(target), 1.0 / 255.0, _p(s["dm1"]), _p(s["dm2"]), _p(s["dm3"]),
-                  _p(s["sums"]), _stream(dev))
+                  _p(sums), _stream(dev))
     else:
         _lib.call("mi3dgs_loss_fwd", Cn, H, W, _p(render), _p(target), _p(s["dm1"]), _p(s["dm2"]), _p(s["dm3"]),
-                  _p(s["sums"]), _stream(dev))
-    return s["sums"], s
+                  _p(sums), _stream(dev))
+    return sums, s
 
 
 def loss_bwd(render, target, scratch, ssim_lambda=0.2, loss_scale=1.0, v_render=None):

@@ -261,7 +261,9 @@ class Trainer:
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=cap, tight=self.cfg.tight_tiles,
                                 fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True, want_tile_keys=False)
-        if self.cfg.auto_isect_capacity and self.cfg.max_isect is None:
+        # (a sample of the steps: the peak only decides when the capacity grows AHEAD of an overflow; an overflow itself sets the
+        #  device error word in whatever step it happens and is absorbed at the next check.  Every step it was one more launch.)
+        if self.cfg.auto_isect_capacity and self.cfg.max_isect is None and (self.step_count & 7) == 0:
             torch.maximum(self._isect_peak, binning["n_isect"], out=self._isect_peak)
         # training steps: the forward leaves checkpoints so that the backward walks long tile lists in segments
         self._seg_ws = ops.raster_seg_workspace(binning, 1, self.device, self.raster_out) if segments else None
@@ -295,10 +297,11 @@ class Trainer:
         if c.random_background:
             bg = torch.rand(1, 3, generator=self.dev_gen, device=self.device)      # (was drawn on the host and copied every step)
         radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg, segments=c.raster_segments)
-        sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch)
+        sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch, want_sums=want_loss)
         ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
+        # (v_splats is clear: zeroed at allocation and at every refine, and the projection backward below clears the rows of the
+        #  visible Gaussians -- the only rows rasterize_bwd writes -- as it reads them; the fill pass was a launch per step)
         v_splats = self.v_splats[:, :n]
-        v_splats.zero_()
         ops.rasterize_bwd(splats, binning, self.W, self.H, alphas, last_ids, self.v_render, self.v_alphas, 16, bg,
                           c.absgrad, v_splats, render=render, seg_ws=self._seg_ws)
         track = c.densify and self.step_count < c.refine_stop_iter
@@ -308,7 +311,7 @@ class Trainer:
         if c.fuse_adam and self._can_fuse_adam():
             ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
                                  [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, viewmat, K, self.W,
-                                 self.H, radii, splats, v_splats, n=n, sh_degree=sd, flags=self._flags(),
+                                 self.H, radii, splats, v_splats, n=n, sh_degree=sd, flags=self._flags() | ops.FLAG_CLEAR_VSPLATS,
                                  beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
                                  scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
                                  scale_reg_max_ratio=c.max_gauss_ratio, stats=stats, stat_use_abs=c.absgrad)
@@ -316,7 +319,7 @@ class Trainer:
             grads = {"v_" + g: m.grad(g) for g in GROUPS}
             ops.project_bwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                             radii, splats, v_splats, sh0=m.p("sh0"), shN=m.p("shN"), color_mode=ops.COLOR_SH,
-                            sh_degree=sd, flags=self._flags(), out=grads, stats=stats, stat_use_abs=c.absgrad)
+                            sh_degree=sd, flags=self._flags() | ops.FLAG_CLEAR_VSPLATS, out=grads, stats=stats, stat_use_abs=c.absgrad)
             if sreg:
                 ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
             self._grad_hooks()
@@ -414,6 +417,7 @@ class Trainer:
         """One densify+prune pass; returns counts.  One host sync (the new Gaussian count)."""
         c, m = self.cfg, self.model
         self.check_async_errors()                    # the host waits here anyway: did every chained kernel resolve?
+        self.v_splats.zero_()                        # (belt and braces: the steps keep it clear themselves, see step())
         n = m.n
         st = ops._stream(self.device)
         flags, counts, offs = self.flags_buf[:n], self.count_buf[:n], self.offs_buf[:n]

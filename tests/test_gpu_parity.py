@@ -312,6 +312,34 @@ def test_loss_fwd_bwd_matches_oracle(dev, C, H, W):
     assert rel_err(v.cpu(), ad.grad) < 1e-4
 
 
+def test_projection_backward_clears_the_gradient_records_it_read(dev):
+    """MI3DGS_FLAG_CLEAR_VSPLATS: same gradients, and afterwards the whole v_splats buffer is zero -- rasterize_bwd writes rows of
+    visible Gaussians only, the projection backward reads exactly those."""
+    ops = _ops()
+    sc = small_scene(n=700, seed=31, big=True, width=96, height=64, n_views=1)
+    sc.params["means"][:100] *= 5.0           # some outside the frustum
+    P = {k: v.to(dev) for k, v in sc.params.items()}
+    vm, K = sc.viewmats.to(dev), sc.Ks.to(dev)
+    fl = ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC
+    radii, splats = ops.project_fwd(P["means"], P["quats"], P["scales"], P["opacities"], vm, K, sc.width, sc.height, sh0=P["sh0"], shN=P["shN"],
+                                    sh_degree=3, flags=fl)
+    b = ops.bin_tiles(radii, splats, sc.width, sc.height, 16)
+    r, a, l = ops.rasterize_fwd(splats, b, sc.width, sc.height, 16)
+    g = torch.Generator().manual_seed(1)
+    vr, va = torch.randn(r.shape, generator=g).to(dev), torch.randn(a.shape, generator=g).to(dev)
+    outs = []
+    for clear in (0, ops.FLAG_CLEAR_VSPLATS):
+        vs = ops.rasterize_bwd(splats, b, sc.width, sc.height, a, l, vr, va, 16)
+        vis = (radii > 0).all(-1)[0]
+        assert float(vs[0][~vis].abs().sum()) == 0.0 and float(vs[0][vis].abs().sum()) > 0
+        out = ops.project_bwd(P["means"], P["quats"], P["scales"], P["opacities"], vm, K, sc.width, sc.height, radii, splats, vs, sh0=P["sh0"],
+                              shN=P["shN"], color_mode=ops.COLOR_SH, sh_degree=3, flags=fl | clear)
+        outs.append({k: v.clone() for k, v in out.items() if torch.is_tensor(v)})
+        assert (float(vs.abs().sum()) == 0.0) == bool(clear)
+    for k in outs[0]:
+        assert rel_err(outs[1][k], outs[0][k]) < 1e-5, k          # (two rasterize_bwd runs: float atomics sum in another order)
+
+
 def test_loss_reads_the_uint8_image_cache_itself(dev):
     """Same bits as converting first (mi3dgs_image_u8_to_f32, value * (1 / 255)) and calling the float32 entry points."""
     ops = _ops()
