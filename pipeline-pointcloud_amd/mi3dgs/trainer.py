@@ -179,6 +179,7 @@ class Trainer:
         self.total_buf = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
         self.dev_gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed + 1)   # per-step draws stay on the device
+        self._bg_table: Optional[torch.Tensor] = None
         self.last: Dict = {}
         self.last_refine: Dict = {}
         self.refine_totals: Dict = {}
@@ -295,7 +296,11 @@ class Trainer:
         sd = self.sh_degree_now()
         bg = None
         if c.random_background:
-            bg = torch.rand(1, 3, generator=self.dev_gen, device=self.device)      # (was drawn on the host and copied every step)
+            # one draw of 8 192 backgrounds at a time, a view of it per step (a torch.rand per step was a launch per step)
+            k = self.step_count & 8191
+            if self._bg_table is None or k == 0:
+                self._bg_table = torch.rand(8192, 1, 3, generator=self.dev_gen, device=self.device)
+            bg = self._bg_table[k]
         radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg, segments=c.raster_segments)
         sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch, want_sums=want_loss)
         ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
