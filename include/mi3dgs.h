@@ -204,8 +204,8 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
  * entries in front of each boundary as work items of their own (512 extra blocks looping over the list, resident from the
  * start of the launch) while the tile's block keeps the rest.  Same gradients up to f32 rounding of (final colour -
  * checkpoint colour), ~1e-5 relative.  Nothing is left for tiles that stop before their first boundary.  Where the capacity
- * exceeds 1 024 entries per tile (lists long everywhere: nothing to balance, and every item has a fixed cost) both calls
- * ignore the workspace.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per
+ * exceeds 1 024 entries per tile on a grid of at least 4 096 tiles (lists long everywhere and blocks enough to fill the device:
+ * nothing to balance, and every item has a fixed cost) both calls ignore the workspace.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per
  * possible boundary (max_isect / 256 of them), touched only where boundaries exist. */
 size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect);
 /* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it.

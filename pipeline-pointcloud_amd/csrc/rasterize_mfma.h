@@ -256,8 +256,8 @@ struct PixelBasis { float u, v, uu, uv, vv; };
 // Segment length: 256 entries (the forward's batch).  Shorter segments balance better (S1 146 -> 118 us, wolf 1280 x 720
 // 199 -> 153 at 256 against 143 / 174 at 512), but every item has a fixed cost, which shows where lists are long and evenly long,
 // i.e. where nothing needed balancing: S2 pays 20 us for 2 373 items at 256, and even its 577 items at 512 only cost (forward
-// +4 us, backward +4 us).  The capacity per tile is the host-side proxy for that regime: above 1 024 entries per tile both
-// rasterisers ignore the workspace (seg_ws_layout returns false) and run as if none had been given.
+// +4 us, backward +4 us).  The capacity per tile is the host-side proxy for that regime: above 1 024 entries per tile, on a grid
+// of at least 4 096 tiles, both rasterisers ignore the workspace (seg_ws_in_use) and run as if none had been given.
 constexpr int SEG_MIN = 256;              // = BLOCK: the forward can only stop at its batch boundaries
 struct SegWs {
     uint32_t* ctl;        // [0] work items handed out
@@ -271,13 +271,17 @@ inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
     const size_t cap = (size_t)(max_isect / SEG_MIN) + 16;       // a boundary has >= SEG_MIN entries of its tile in front of it
     return 512 + (((size_t)n_tiles * 4 + 255) & ~(size_t)255) + cap * (16 + BLOCK * 16);
 }
-// capacity per tile above which the workspace is not used (lists long everywhere: nothing to balance)
+// The workspace is not used where lists are long everywhere AND there are tiles enough to fill the device many times over
+// (S2, S3: nothing to balance).  Few tiles with long lists are the opposite case: the first 3 000 steps of an ns-train run render
+// at a quarter of the resolution -- 180 tiles for 256 CUs, thousands of entries each -- and the serial walk took 253 us there.
 constexpr size_t SEG_OFF_ENTRIES_PER_TILE = 1024;
+constexpr int SEG_OFF_MIN_TILES = 4096;
 inline bool seg_ws_in_use(int n_tiles, size_t bytes) {
     const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255, fixed = 512 + nb_bytes;
     if (bytes < fixed + (16 + BLOCK * 16)) return false;
     const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
-    return (cap > 16 ? cap - 16 : 0) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) <= SEG_OFF_ENTRIES_PER_TILE;
+    const bool long_everywhere = (cap > 16 ? cap - 16 : 0) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) > SEG_OFF_ENTRIES_PER_TILE;
+    return !(long_everywhere && n_tiles >= SEG_OFF_MIN_TILES);
 }
 // both rasterisers derive the same views from (n_tiles, bytes)
 inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {

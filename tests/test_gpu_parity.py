@@ -243,8 +243,7 @@ def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, b
     at its 512-entry boundaries and the backward walks the segments as work items of their own.  Held to the autograd oracle
     like every other backward, and to the one-block-per-tile walk of the same library (segments=False)."""
     import mi3dgs
-    # (a blob of 8 000 faint splats in the middle of a 192 x 160 frame: a dozen tiles with lists thousands long among 120 -- above
-    #  1 024 entries per tile of CAPACITY the library takes the lists to be long everywhere and ignores the workspace)
+    # (a blob of 8 000 faint splats in the middle of a 192 x 160 frame: a dozen tiles with lists thousands long among 120)
     sc = small_scene(n=8000, seed=21, big=True, width=192, height=160, n_views=n_views)
     g = torch.Generator().manual_seed(5)
     sc.params["opacities"] = torch.rand(8000, generator=g) * 1.5 - 5.0          # alpha 0.7 .. 3 %: lists are walked deep
@@ -272,7 +271,7 @@ def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, b
     n_items = int(metas[0]["seg_ws"][:4].view(torch.int32)[0].item())
     n_tiles = off.numel()
     assert int(off.diff().max()) > 3000 and n_items >= 20 * n_views and metas[1]["seg_ws"] is None, (int(off.diff().max()), n_items)
-    assert int(metas[0]["n_isect"].item()) <= 1024 * n_tiles, "the case must stay below the capacity at which segments switch off"
+    assert n_tiles < 4096, "segments switch off for long lists on big grids only"
     for k in ("means", "quats", "scales", "opacities", "sh"):
         e_seg, e_ser = rel_err(grads[0][k], leaves[k].grad), rel_err(grads[1][k], leaves[k].grad)
         assert e_seg < 2e-3 and e_ser < 2e-3, (k, e_seg, e_ser)
