@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
+    ap.add_argument("--no-spatial-sort", action="store_true", help="A/B: keep the generator's (random) order of the Gaussians")
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
@@ -118,7 +119,9 @@ def build_workload(args, rank, dev):
         # step); the every-100-steps refine pass is NOT inside the timed steps -- main() times one
         # refine() after them and reports `refine_ms` and the amortised rate next to `value`
         refine_start_iter=10 ** 9,
-        max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning)
+        max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning,
+        # the trainer's load-time Morton ordering of the Gaussians, as the CLI runs it (TrainConfig.spatial_sort_init)
+        spatial_sort_init=not args.no_spatial_sort)
     if args.mode == "scene-shard":
         import dataclasses
         from mi3dgs import parallel
@@ -556,7 +559,7 @@ def main():
             "data": "synthetic", "box": box,
             "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, {what}",
                        "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
-                       "parallelism": par, "mode": args.mode,
+                       "parallelism": par, "mode": args.mode, "gaussians_in_morton_order": bool(tr.cfg.spatial_sort_init),
                        "xgmi_bytes_per_rank_per_step": tr.xgmi_bytes_per_step() if shard else 0},
             "render_fps": fps, "roofline": roof, "render_roofline": render_roof, "refine": refine,
             "async_errors": async_bits, "cpu_baseline": cpu, "stages": stages,

@@ -81,6 +81,11 @@ class TrainConfig:
     fused_binning: bool = True
     # the backward walks tile lists longer than 512 entries in segments, from checkpoints the forward leaves (include/mi3dgs.h)
     raster_segments: bool = True
+    # order the initial Gaussians along a Morton curve of their positions (a permutation: same training up to float summation
+    # order).  Neighbours in memory are then neighbours in space: a wave of the projection kernels is culled or visible as a
+    # whole, and the rasterisers' record gathers hit the cache.  Refinement keeps children next to their parents, so the order
+    # survives.  Off by default (callers that compare parameters by index); the CLI and bench.py switch it on.
+    spatial_sort_init: bool = False
     # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
     # gradients for its all-reduce and switches this off)
     fuse_adam: bool = True
@@ -143,10 +148,29 @@ class GaussianModel:
         return {g: self.p(g).detach().clone() for g in GROUPS}
 
 
+def morton_order(means: torch.Tensor) -> torch.Tensor:
+    """Indices that order [N,3] positions along a 30-bit Morton curve of their bounding box (ties keep their order)."""
+    m = means.detach().reshape(-1, 3).double()
+    lo, hi = m.min(0).values, m.max(0).values
+    q = ((m - lo) / (hi - lo).clamp(min=1e-30) * 1023.999).long().clamp(0, 1023)
+
+    def spread(x):          # 10 bits -> every third bit
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.sort(code, stable=True).indices
+
+
 class Trainer:
     def __init__(self, params: Dict[str, torch.Tensor], viewmats: torch.Tensor, Ks: torch.Tensor,
                  images: torch.Tensor, width: int, height: int, cfg: Optional[TrainConfig] = None):
         self.cfg = cfg or TrainConfig()
+        if self.cfg.spatial_sort_init and params["means"].shape[0] > 1:
+            perm = morton_order(params["means"])
+            params = {k: v[perm.to(v.device)] for k, v in params.items()}
         self.model = GaussianModel(params, self.cfg.capacity, **self._model_layout())
         dev = self.model.device
         self.device = dev
