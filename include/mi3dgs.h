@@ -208,6 +208,11 @@ int mi3dgs_rasterize_fwd(int C, int width, int height, int tile_size, int tile_w
  * nothing to balance, and every item has a fixed cost) both calls ignore the workspace.  Size: mi3dgs_raster_seg_workspace_bytes(C * tile_width * tile_height, max_isect) -- 4 KB per
  * possible boundary (max_isect / 256 of them), touched only where boundaries exist. */
 size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect);
+/* Clears the workspace's control words.  Call it once after allocating the workspace.  Every mi3dgs_rasterize_bwd given the
+ * workspace leaves them clear again (its workers reset the counter they consumed), so a training loop -- forward, backward,
+ * forward, backward -- never clears anything; call it again before a forward only if the forward before it was NOT followed by
+ * its backward (the counter would still hold that forward's work items). */
+int mi3dgs_raster_seg_workspace_init(void* seg_workspace, size_t seg_workspace_bytes, void* stream);
 /* v_splats[C*N][16] must be zeroed by the caller; gradients are ACCUMULATED into it.
  * Numerics: log2 alpha of a (pixel, splat) pair is evaluated by the forward's own instruction sequence (three-term bf16
  * coefficients against an exact bf16 basis, f32 accumulation), so forward and backward take the same alpha >= 1/255 decision;

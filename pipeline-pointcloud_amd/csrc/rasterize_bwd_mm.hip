@@ -554,13 +554,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands, int n_workers,
     SegWs seg, const float* __restrict__ render) {
     __shared__ StagedBwdMM<ABSGRAD, SH> L;
+    __shared__ int s_items;
     int item = (int)blockIdx.x < n_workers ? (int)blockIdx.x : -1;            // < 0: a tile's own block
     int t = -1, n_items = 0;
     if (item < 0) {
         t = tile_of_block((int)blockIdx.x - n_workers, n_tiles_total, bands, tw);
         if (t < 0) return;
     } else {
-        n_items = (int)min(seg.ctl[0], seg.cap);
+        // The workers leave the counter clear for the next forward: one thread per worker reads it and counts itself in; the
+        // last one to do so resets both words (every reader has read by then).  A clear per forward was a launch per step.
+        if (threadIdx.x == 0) {
+            s_items = (int)min(__hip_atomic_load(&seg.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seg.cap);
+            if (__hip_atomic_fetch_add(&seg.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)n_workers - 1u) {
+                __hip_atomic_store(&seg.ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&seg.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        n_items = s_items;
     }
     for (;;) {
         if (item >= 0) {

@@ -347,8 +347,8 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
     SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (seg_ws) {
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_fwd: segment workspace too small (mi3dgs_raster_seg_workspace_bytes)");
+        // (the work counter is clear: mi3dgs_raster_seg_workspace_init once, and every backward leaves it clear again)
         if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
-        else MI_HIP(hipMemsetAsync(seg.ctl, 0, 64, st));
     }
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
@@ -395,4 +395,10 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
 extern "C" size_t mi3dgs_raster_seg_workspace_bytes(int n_tiles, long long max_isect) {
     if (n_tiles <= 0 || max_isect < 0) return 0;
     return mfma_raster::seg_ws_bytes_for(n_tiles, max_isect);
+}
+
+extern "C" int mi3dgs_raster_seg_workspace_init(void* seg_workspace, size_t seg_workspace_bytes, void* stream) {
+    MI_REQUIRE(seg_workspace && seg_workspace_bytes >= 256, "raster_seg_workspace_init: no workspace");
+    MI_HIP(hipMemsetAsync(seg_workspace, 0, 256, (hipStream_t)stream));
+    return 0;
 }

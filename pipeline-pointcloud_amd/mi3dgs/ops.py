@@ -221,6 +221,8 @@ def raster_seg_workspace(binning, Cn, device, out=None):
     ws = out.get("seg_ws") if out is not None else None
     if ws is None or ws.numel() < nbytes or ws.device != device:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # control words cleared once; every rasterize_bwd given the workspace leaves them clear for the next forward
+        _lib.call("mi3dgs_raster_seg_workspace_init", _p(ws), ws.numel(), _stream(device))
         if out is not None:
             out["seg_ws"] = ws
     # exactly the size of THIS call's lists: both rasterisers derive the layout (and whether lists are long enough everywhere

@@ -263,12 +263,15 @@ def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, b
                                           sc.Ks.to(dev), sc.width, sc.height, sh_degree=3,
                                           backgrounds=None if bgs is None else bgs.float().to(dev), absgrad=absgrad,
                                           segments=segments)
+        if segments:          # work items the forward left; the backward's workers leave the counter clear for the next forward
+            n_items = int(meta["seg_ws"][:4].view(torch.int32)[0].item())
         ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
+        if segments:
+            assert int(meta["seg_ws"][:8].view(torch.int32).abs().sum().item()) == 0
         grads.append({k: gl[k].grad.cpu() for k in gl})
         metas.append(meta)
     # the case is what it claims to be: every tile's list is thousands long and hundreds of boundaries were walked past
     off = metas[0]["isect_offsets"].flatten().cpu()
-    n_items = int(metas[0]["seg_ws"][:4].view(torch.int32)[0].item())
     n_tiles = off.numel()
     assert int(off.diff().max()) > 3000 and n_items >= 20 * n_views and metas[1]["seg_ws"] is None, (int(off.diff().max()), n_items)
     assert n_tiles < 4096, "segments switch off for long lists on big grids only"
