@@ -343,6 +343,37 @@ def test_the_two_backward_rasterisers_agree_at_full_size(dev, kind, cam, absgrad
     assert ops._lib.async_errors() == 0
 
 
+@pytest.mark.parametrize("kind,cam,absgrad", [("lego", 3, False), ("lego", 5, True)])
+def test_backward_in_segments_agrees_with_the_serial_walk_at_full_size(dev, kind, cam, absgrad):
+    """S1, full frame: the forward with the segment workspace leaves hundreds of checkpoints, the backward walks the segments as work
+    items of their own (WIDE shape) -- same gradient records as one block per tile, up to the float32 rounding of
+    (final colour - checkpoint colour) and the order of the float atomics; and the counter is clear again afterwards."""
+    ops = _ops()
+    sc = _scene(kind)
+    W, H = sc.width, sc.height
+    g, vm, K, radii, splats, keys = _project(sc, dev, cam, want_keys=True)
+    b = ops.bin_tiles(radii, splats, W, H, 16, tight=True)
+    bg = torch.tensor([[0.3, 0.6, 0.1]], device=dev)
+    gen = torch.Generator().manual_seed(10)
+    vr = (torch.rand(1, H, W, 3, generator=gen) - 0.5).to(dev)
+    va = (torch.rand(1, H, W, 1, generator=gen) - 0.5).to(dev)
+    r0, a0, l0 = [t.clone() for t in ops.rasterize_fwd(splats, b, W, H, 16, bg, {})]
+    serial = ops.rasterize_bwd(splats, b, W, H, a0, l0, vr, va, 16, bg, absgrad).clone()
+    ws = ops.raster_seg_workspace(b, 1, dev)
+    r1, a1, l1 = ops.rasterize_fwd(splats, b, W, H, 16, bg, {}, seg_ws=ws)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(l0, l1)          # the checkpoints change nothing in the forward
+    n_items = int(ws[:4].view(torch.int32)[0].item())
+    assert n_items > 100, n_items
+    seg = ops.rasterize_bwd(splats, b, W, H, a1, l1, vr, va, 16, bg, absgrad, render=r1, seg_ws=ws)
+    assert int(ws[:8].view(torch.int32).abs().sum().item()) == 0
+    ncol = 11 if absgrad else 9
+    assert bool(torch.isfinite(seg).all())
+    for c in range(ncol):
+        x, y = seg[0, :, c].double(), serial[0, :, c].double()
+        assert float((x - y).norm() / y.norm().clamp(min=1e-30)) < 3e-4, (c, float((x - y).norm() / y.norm()))
+    assert ops._lib.async_errors() == 0
+
+
 def test_s2_training_step_properties_and_fused_adam(dev):
     """One whole training step of the bench configuration (2 M Gaussians, 1080p, capacity mode, fused
     binning, fused backward + Adam) against the unfused sequence on the same inputs; then the properties."""
