@@ -57,6 +57,8 @@ def parse():
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
     ap.add_argument("--no-spatial-sort", action="store_true", help="A/B: keep the generator's (random) order of the Gaussians")
+    ap.add_argument("--overlap-adam", default="off", choices=["off", "after_project", "after_binning"],
+                    help="A/B: Adam of the fully culled 64-Gaussian groups on a second stream, under the rasterisers")
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
@@ -121,7 +123,8 @@ def build_workload(args, rank, dev):
         refine_start_iter=10 ** 9,
         max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning,
         # the trainer's load-time Morton ordering of the Gaussians, as the CLI runs it (TrainConfig.spatial_sort_init)
-        spatial_sort_init=not args.no_spatial_sort)
+        spatial_sort_init=not args.no_spatial_sort,
+        overlap_culled_adam=None if args.overlap_adam == "off" else args.overlap_adam)
     if args.mode == "scene-shard":
         import dataclasses
         from mi3dgs import parallel

@@ -47,6 +47,13 @@ extern "C" {
                                       that the next step's rasterize_bwd finds the buffer clear without a fill pass of its own.
                                       The buffer is written through the `const` pointer: it must be writable. */
 
+/* mi3dgs_project_bwd_adam only: the call handles only the aligned 64-Gaussian groups NONE of whose members is visible (their
+ * update needs no gradient: a pure Adam stream over their parameters, which depends on mi3dgs_project_fwd's radii alone), or
+ * only the groups with a visible member.  Two calls, one with each bit, update every Gaussian exactly once: the first can run on a
+ * second stream under the rasterisers (which leave HBM idle) while the second waits for mi3dgs_rasterize_bwd. */
+#define MI3DGS_FLAG_ONLY_CULLED_GROUPS 16
+#define MI3DGS_FLAG_ONLY_VISIBLE_GROUPS 32
+
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
 #define MI3DGS_COLOR_PER_GAUSSIAN 1 /* colors[N,3] */

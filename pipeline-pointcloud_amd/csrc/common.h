@@ -42,6 +42,8 @@
 #define MI_FLAG_LOGIT_OPAC 2      // opacities are logits (sigmoid applied in-kernel)
 #define MI_FLAG_ANTIALIASED 4     // rasterize_mode == "antialiased": opacity *= compensation
 #define MI_FLAG_CLEAR_VSPLATS 8   // project_bwd / project_bwd_adam (one camera, SH): a visible Gaussian's v_splats row is zeroed once read
+#define MI_FLAG_ONLY_CULLED_WAVES 16   // project_bwd_adam: only the 64-Gaussian groups none of whose members is visible (a pure Adam stream)
+#define MI_FLAG_ONLY_VISIBLE_WAVES 32  // project_bwd_adam: only the groups with a visible member
 #define MI_BIN_TIGHT 1             // mi3dgs_bin_*: `tight` argument, bit 0 = exact ellipse culling
 #define MI_BIN_RADII_IN_RECORDS 2  //   bit 1 = take the radii from record slots SP_RX / SP_RY (written by project_fwd)
 #define MI_BIN_KEYS_SCRATCH 4      //   bit 2 (mi3dgs_bin_tiles) = the caller does not read tile_keys back: the buffer is scratch (16-bit keys)

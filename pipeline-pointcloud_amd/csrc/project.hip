@@ -610,7 +610,9 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     int2 rad = make_int2(0, 0);
     if (live) rad = *reinterpret_cast<const int2*>(radii + 2 * (long long)n);
     const bool vis = live && rad.x > 0 && rad.y > 0;
-    const bool need_coef = sh_degree >= 1 && wave_ballot(vis) != 0ull;
+    const bool any_vis = wave_ballot(vis) != 0ull;
+    if (FUSE && (((flags & MI_FLAG_ONLY_CULLED_WAVES) && any_vis) || ((flags & MI_FLAG_ONLY_VISIBLE_WAVES) && !any_vis))) return;
+    const bool need_coef = sh_degree >= 1 && any_vis;
     // FUSE: the lane that stages float4 number i4 of the slice is also the lane that applies Adam to
     // it at the end, so the coefficients stay in 48 registers instead of being read from HBM twice
     // (the kernel sits at 3 waves per SIMD because of its LDS, which leaves 168 VGPRs).

@@ -22,6 +22,8 @@ FLAG_LOG_SCALES = 1
 FLAG_LOGIT_OPAC = 2
 FLAG_ANTIALIASED = 4
 FLAG_CLEAR_VSPLATS = 8      # project_bwd / project_bwd_adam: clear the v_splats rows they read (include/mi3dgs.h)
+FLAG_ONLY_CULLED_GROUPS = 16     # project_bwd_adam: only the 64-Gaussian groups without a visible member (pure Adam stream)
+FLAG_ONLY_VISIBLE_GROUPS = 32    # project_bwd_adam: only the groups with one
 COLOR_SH, COLOR_PER_GAUSSIAN, COLOR_PER_CAMERA = 0, 1, 2
 
 

@@ -86,6 +86,11 @@ class TrainConfig:
     # whole, and the rasterisers' record gathers hit the cache.  Refinement keeps children next to their parents, so the order
     # survives.  Off by default (callers that compare parameters by index); the CLI and bench.py switch it on.
     spatial_sort_init: bool = False
+    # fused single-GPU path: the Adam update of the 64-Gaussian groups none of whose members is visible needs no gradient; it is
+    # launched on a second stream right after the binning and streams under the rasterisers (which leave HBM idle) instead of
+    # after them.  Same update for every Gaussian, exactly once; pays where many groups are culled as a whole, i.e. with the
+    # Gaussians in Morton order (spatial_sort_init).  "after_project" / "after_binning": where the side launch is issued.
+    overlap_culled_adam: Optional[str] = None
     # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
     # gradients for its all-reduce and switches this off)
     fuse_adam: bool = True
@@ -204,6 +209,7 @@ class Trainer:
         self.gen = torch.Generator(device="cpu").manual_seed(self.cfg.seed)
         self.dev_gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed + 1)   # per-step draws stay on the device
         self._bg_table: Optional[torch.Tensor] = None
+        self._side_stream = None
         self.last: Dict = {}
         self.last_refine: Dict = {}
         self.refine_totals: Dict = {}
@@ -273,7 +279,7 @@ class Trainer:
         lr_means = c.lr_means * c.scene_scale * (c.lr_means_final_ratio ** t)
         return (lr_means, c.lr_quats, c.lr_scales, c.lr_opacities, c.lr_sh0, c.lr_shN)
 
-    def _forward(self, viewmat, K, sh_degree, background=None, exact_isect=False, segments=False):
+    def _forward(self, viewmat, K, sh_degree, background=None, exact_isect=False, segments=False, hooks=None):
         m, n = self.model, self._n()
         radii, splats = self.radii[:, :n], self.splats[:, :n]
         cap = self.cfg.max_isect
@@ -284,8 +290,12 @@ class Trainer:
         ops.project_fwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,
                         sh0=m.p("sh0"), shN=m.p("shN"), sh_degree=sh_degree, near_plane=self.cfg.near_plane,
                         far_plane=self.cfg.far_plane, flags=self._flags(), radii=radii, splats=splats, depth_keys=keys)
+        if hooks and "after_project" in hooks:
+            hooks["after_project"](radii, splats)
         binning = ops.bin_tiles(radii, splats, self.W, self.H, 16, max_isect=cap, tight=self.cfg.tight_tiles,
                                 fused=self.cfg.fused_binning, depth_keys=keys, radii_in_records=True, want_tile_keys=False)
+        if hooks and "after_binning" in hooks:
+            hooks["after_binning"](radii, splats)
         # (a sample of the steps: the peak only decides when the capacity grows AHEAD of an overflow; an overflow itself sets the
         #  device error word in whatever step it happens and is absorbed at the next check.  Every step it was one more launch.)
         if self.cfg.auto_isect_capacity and self.cfg.max_isect is None and (self.step_count & 7) == 0:
@@ -325,7 +335,33 @@ class Trainer:
             if self._bg_table is None or k == 0:
                 self._bg_table = torch.rand(8192, 1, 3, generator=self.dev_gen, device=self.device)
             bg = self._bg_table[k]
-        radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg, segments=c.raster_segments)
+        fused = c.fuse_adam and self._can_fuse_adam()
+        sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
+        split = fused and c.overlap_culled_adam in ("after_project", "after_binning")
+        hooks = None
+        if split:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._ev_main, self._ev_side = torch.cuda.Event(), torch.cuda.Event()
+
+            def culled_groups(radii_, splats_):
+                # (needs this step's radii; touches the parameters and moments of fully culled groups only, which nothing else
+                #  reads or writes until the next step's projection)
+                self._ev_main.record(torch.cuda.current_stream(self.device))
+                self._side_stream.wait_event(self._ev_main)
+                with torch.cuda.stream(self._side_stream):
+                    bank_ = m.banks[m.cur]
+                    ops.project_bwd_adam([bank_[g]["p"] for g in GROUPS], [bank_[g]["m"] for g in GROUPS],
+                                         [bank_[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, viewmat, K, self.W,
+                                         self.H, radii_, splats_, self.v_splats[:, :n], n=n, sh_degree=sd,
+                                         flags=self._flags() | ops.FLAG_ONLY_CULLED_GROUPS,
+                                         beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                                         scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
+                                         scale_reg_max_ratio=c.max_gauss_ratio, stats=None, stat_use_abs=c.absgrad)
+                    self._ev_side.record(self._side_stream)
+
+            hooks = {c.overlap_culled_adam: culled_groups}
+        radii, splats, binning, render, alphas, last_ids = self._forward(viewmat, K, sd, bg, segments=c.raster_segments, hooks=hooks)
         sums, scratch = ops.loss_fwd(render, gt, self.loss_scratch, want_sums=want_loss)
         ops.loss_bwd(render, gt, scratch, c.ssim_lambda, 1.0, self.v_render)
         # (v_splats is clear: zeroed at allocation and at every refine, and the projection backward below clears the rows of the
@@ -335,15 +371,17 @@ class Trainer:
                           c.absgrad, v_splats, render=render, seg_ws=self._seg_ws)
         track = c.densify and self.step_count < c.refine_stop_iter
         stats = {k: v[:n] for k, v in self.stats.items()} if track else None
-        sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
         bank = m.banks[m.cur]
-        if c.fuse_adam and self._can_fuse_adam():
+        if fused:
             ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
                                  [bank[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, viewmat, K, self.W,
-                                 self.H, radii, splats, v_splats, n=n, sh_degree=sd, flags=self._flags() | ops.FLAG_CLEAR_VSPLATS,
+                                 self.H, radii, splats, v_splats, n=n, sh_degree=sd,
+                                 flags=self._flags() | ops.FLAG_CLEAR_VSPLATS | (ops.FLAG_ONLY_VISIBLE_GROUPS if split else 0),
                                  beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
                                  scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
                                  scale_reg_max_ratio=c.max_gauss_ratio, stats=stats, stat_use_abs=c.absgrad)
+            if split:          # the next step's projection reads every parameter
+                torch.cuda.current_stream(self.device).wait_event(self._ev_side)
         else:
             grads = {"v_" + g: m.grad(g) for g in GROUPS}
             ops.project_bwd(m.p("means"), m.p("quats"), m.p("scales"), m.p("opacities"), viewmat, K, self.W, self.H,

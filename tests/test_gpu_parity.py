@@ -489,6 +489,37 @@ def test_training_recovers_target(dev):
     assert last < 0.5 * first, (first, last)
 
 
+def test_culled_groups_adam_on_a_second_stream_is_the_same_update(dev):
+    """TrainConfig.overlap_culled_adam: the fused backward + Adam as two launches (fully culled 64-Gaussian groups on a side stream
+    after the projection, the others after the rasteriser) updates every Gaussian exactly as the one launch does."""
+    from mi3dgs import trainer
+    sc = small_scene(n=6000, seed=13, big=False, width=96, height=64, n_views=4, fx=90.0)
+    sc.params["means"][:2500] += torch.tensor([30.0, 0.0, 0.0])          # a good part of the scene outside every view
+    g = sc.to(dev)
+    tr0 = trainer.Trainer(g.params, g.viewmats, g.Ks, torch.zeros(4, 64, 96, 3, device=dev), 96, 64, trainer.TrainConfig(densify=False))
+    imgs = torch.cat([tr0.render(g.viewmats[i], g.Ks[i])[0].clone() for i in range(4)])
+    gen = torch.Generator().manual_seed(9)
+    P = {k: v.clone() for k, v in g.params.items()}
+    P["sh0"] = P["sh0"] + 0.2 * torch.randn(6000, 1, 3, generator=gen).to(dev)
+    out = []
+    for mode in (None, "after_project", "after_binning"):
+        cfg = trainer.TrainConfig(max_steps=300, densify=False, sh_degree_interval=1, spatial_sort_init=True, overlap_culled_adam=mode,
+                                  use_scale_regularization=True, scale_reg_every=3)
+        tr = trainer.Trainer(P, g.viewmats, g.Ks, imgs, 96, 64, cfg)
+        for i in range(12):
+            tr.step(i % 4)
+        torch.cuda.synchronize()
+        vis = (tr.radii[0, :6000] > 0).all(-1)
+        out.append(({k: tr.model.p(k).clone() for k in trainer.GROUPS}, {k: tr.model.state(k, "m").clone() for k in trainer.GROUPS}, vis))
+    never = ~out[0][2]              # (culled in the last view; the far block is culled in every view)
+    assert 64 * 20 < int(never.sum()) < 6000 - 64 * 20
+    far = torch.zeros(6000, dtype=torch.bool, device=dev)
+    far[:0] = False
+    for k in trainer.GROUPS:
+        for o in out[1:]:
+            assert rel_err(o[0][k], out[0][0][k]) < 2e-3 and rel_err(o[1][k], out[0][1][k]) < 2e-3, k
+
+
 def test_morton_ordered_start_trains_the_same_gaussians(dev):
     """TrainConfig.spatial_sort_init permutes the initial Gaussians along a Morton curve: the same training, Gaussian for Gaussian,
     up to the order in which float atomics meet (including a refine pass, which keeps children next to their parents)."""
