@@ -57,8 +57,9 @@ def parse():
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
     ap.add_argument("--no-spatial-sort", action="store_true", help="A/B: keep the generator's (random) order of the Gaussians")
-    ap.add_argument("--overlap-adam", default="off", choices=["off", "after_project", "after_binning"],
-                    help="A/B: Adam of the fully culled 64-Gaussian groups on a second stream, under the rasterisers")
+    ap.add_argument("--overlap-adam", default="after_binning", choices=["off", "after_project", "after_binning", "after_raster_fwd"],
+                    help="Adam of the fully culled 64-Gaussian groups on a second stream (TrainConfig.overlap_culled_adam, as the CLI "
+                         "runs it); off / other launch points for the A/B")
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()

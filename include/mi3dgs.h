@@ -54,6 +54,15 @@ extern "C" {
 #define MI3DGS_FLAG_ONLY_CULLED_GROUPS 16
 #define MI3DGS_FLAG_ONLY_VISIBLE_GROUPS 32
 
+/* The update of the fully culled groups as a kernel of its own (a pure stream: no gradient, ~30 registers, no LDS -- it fits
+ * beside the rasterisers' and the loss kernels' waves on a second stream): the same bits as mi3dgs_project_bwd_adam gives those
+ * Gaussians.  params / exp_avg / exp_avg_sq: HOST arrays of 6 device pointers (group order of mi3dgs_project_bwd_adam, 16-byte
+ * aligned; opacities may be NULL in all three); radii[N][2]: this step's mi3dgs_project_fwd output, one camera.  Follow it with
+ * mi3dgs_project_bwd_adam(..., flags | MI3DGS_FLAG_ONLY_VISIBLE_GROUPS, ...) with no scale regulariser in that step. */
+int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                              const int32_t* radii, const float* lrs, int step, float beta1, float beta2, float eps,
+                              void* stream);
+
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
 #define MI3DGS_COLOR_PER_GAUSSIAN 1 /* colors[N,3] */

@@ -151,6 +151,88 @@ extern "C" int mi3dgs_adam_step(int nseg, float* const* params, const float* con
     return 0;
 }
 
+// ---- Adam of the 64-Gaussian groups none of whose members is visible.  Their gradient is zero, so their update needs nothing
+// but mi3dgs_project_fwd's radii: a pure stream over parameters and moments.  As a kernel of its own -- thirty-odd registers,
+// no LDS -- it fits on SIMDs beside the forward rasteriser's and the loss kernels' waves (which leave HBM idle), on a second
+// stream; mi3dgs_project_bwd_adam with MI3DGS_FLAG_ONLY_VISIBLE_GROUPS then handles the other groups after rasterize_bwd.
+// The arithmetic is the fused kernel's for a Gaussian it finds invisible: mi_adam1 with a zero gradient and the same per-step
+// scalars (lr / (1 - b1^t) formed in double on the host), so every Gaussian gets the same bits whichever kernel updates it.
+namespace {
+struct AdamGroupsArgs {
+    float* p[6]; float* m[6]; float* v[6];
+    float step_size[6];
+    float b1, b2, eps, inv_bc2_sqrt, zero;
+};
+
+__global__ __launch_bounds__(256) void adam_culled_groups_kernel(int N, const int32_t* __restrict__ radii, AdamGroupsArgs A) {
+    const int lane = lane_id();
+    const long long n0 = ((long long)blockIdx.x * 256 + threadIdx.x - lane);          // first Gaussian of this wave's group
+    if (n0 >= N) return;
+    const int cnt = (int)min((long long)64, (long long)N - n0);
+    bool vis = false;
+    if (lane < cnt) {
+        const int2 r = *reinterpret_cast<const int2*>(radii + 2 * (n0 + lane));
+        vis = r.x > 0 && r.y > 0;
+    }
+    if (wave_ballot(vis) != 0ull) return;
+    // (the loop over the groups is NOT unrolled: the kernel should stay small enough in registers to sit beside other kernels)
+    const int W_[6] = {3, 4, 3, 1, 3, 45};
+#pragma unroll 1
+    for (int gi = 0; gi < 6; gi++) {
+        if (A.p[gi] == nullptr) continue;                     // (no opacity array)
+        const int total = cnt * W_[gi];
+        const long long base = n0 * W_[gi];                  // multiple of 4 floats: 64 Gaussians x any width
+        float4* p4 = reinterpret_cast<float4*>(A.p[gi] + base);
+        float4* m4 = reinterpret_cast<float4*>(A.m[gi] + base);
+        float4* v4 = reinterpret_cast<float4*>(A.v[gi] + base);
+        const int n4 = total >> 2;
+        const float ss = A.step_size[gi];
+        // (one float4 of each array per lane at a time: the kernel's job is to fit on SIMDs whose registers are nearly all taken;
+        //  the bandwidth comes from the number of waves that do)
+#pragma unroll 1
+        for (int i4 = lane; i4 < n4; i4 += 64) {
+            float4 pa = p4[i4], ma = m4[i4], va = v4[i4];
+            mi_adam1(pa.x, A.zero, ma.x, va.x, ss, A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            mi_adam1(pa.y, A.zero, ma.y, va.y, ss, A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            mi_adam1(pa.z, A.zero, ma.z, va.z, ss, A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            mi_adam1(pa.w, A.zero, ma.w, va.w, ss, A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            p4[i4] = pa; m4[i4] = ma; v4[i4] = va;
+        }
+        for (int e = 4 * n4 + lane; e < total; e += 64) {      // (a last group of fewer than 64 Gaussians)
+            float pp = A.p[gi][base + e], mm = A.m[gi][base + e], vv = A.v[gi][base + e];
+            mi_adam1(pp, A.zero, mm, vv, ss, A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+            A.p[gi][base + e] = pp; A.m[gi][base + e] = mm; A.v[gi][base + e] = vv;
+        }
+    }
+}
+}  // namespace
+
+// params / exp_avg / exp_avg_sq: HOST arrays of 6 device pointers in the group order of mi3dgs_project_bwd_adam (opacities may be
+// null in all three); radii[N][2] of this step's mi3dgs_project_fwd (one camera).
+extern "C" int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                         const int32_t* radii, const float* lrs, int step, float beta1, float beta2, float eps,
+                                         void* stream) {
+    MI_REQUIRE(N >= 0 && params && exp_avg && exp_avg_sq && radii && lrs, "adam_culled_groups: null argument");
+    MI_REQUIRE(step >= 1, "adam_culled_groups: step is 1-based");
+    if (N == 0) return 0;
+    AdamGroupsArgs A;
+    uintptr_t align = 0;
+    for (int g = 0; g < 6; g++) {
+        A.p[g] = params[g]; A.m[g] = exp_avg[g]; A.v[g] = exp_avg_sq[g];
+        MI_REQUIRE((params[g] != nullptr) == (exp_avg[g] != nullptr) && (params[g] != nullptr) == (exp_avg_sq[g] != nullptr),
+                   "adam_culled_groups: a group needs all three arrays or none");
+        MI_REQUIRE(params[g] != nullptr || g == 3, "adam_culled_groups: only the opacity group may be absent");
+        align |= (uintptr_t)params[g] | (uintptr_t)exp_avg[g] | (uintptr_t)exp_avg_sq[g];
+    }
+    MI_REQUIRE((align & 15) == 0, "adam_culled_groups: arrays must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    for (int g = 0; g < 6; g++) A.step_size[g] = (float)(lrs[g] / bc1);
+    A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); A.zero = 0.f;
+    MI_LAUNCH("adam_culled", adam_culled_groups_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, radii, A);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- HBM yardstick.  What a plain 16-byte-per-lane stream gets from THIS device, measured by the bench itself
 // (bench.py: roofline.copy_GBps_this_box) instead of being assumed: NR arrays are read, their sum is written to NW arrays;
 // every array is `n4` float4 long and lives in `buf` one after the other (reads first).  (1, 1) is the float4 copy of

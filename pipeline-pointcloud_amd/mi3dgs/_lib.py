@@ -59,6 +59,7 @@ _SIGNATURES = {
     "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _ll, _f, _f, _sz, _f]),
     "mi3dgs_raster_seg_workspace_bytes": (_sz, [_i, _ll]),
     "mi3dgs_raster_seg_workspace_init": (_i, [_f, _sz, _f]),
+    "mi3dgs_adam_culled_groups": (_i, [_i, _f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _f]),
     "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_loss_fwd_u8": (_i, [_i, _i, _i, _f, _f, _fl, _f, _f, _f, _f, _f]),

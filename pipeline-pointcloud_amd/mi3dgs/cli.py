@@ -123,7 +123,7 @@ def splatfacto_config(model: str, max_steps: int, scale_reg: bool, n_train: int,
         prune_opa=0.005 if big else 0.1, grow_grad2d=0.0005 if big else 0.0008, grow_scale3d=0.01, prune_scale3d=0.5,
         refine_start_iter=500, refine_stop_iter=15000, reset_every=3000, refine_every=100,
         pause_refine_after_reset=n_train + 100, absgrad=True, use_scale_regularization=scale_reg,
-        random_background=True, capacity=capacity, auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True,
+        random_background=True, capacity=capacity, auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True, overlap_culled_adam="after_binning",
         num_downscales=2, resolution_schedule=3000)          # splatfacto: 1/4 -> 1/2 -> full, every 3000 steps
 
 
@@ -132,7 +132,7 @@ def simple_trainer_config(a: Dict, capacity: int):
     cfg = TrainConfig(max_steps=a["max_steps"], capacity=capacity, antialiased=a["antialiased"],
                       random_background=a["random_bkgd"], absgrad=a["absgrad"],
                       grow_grad2d=0.0008 if a["absgrad"] else 0.0002, scene_scale=1.1,
-                      auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True)
+                      auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True, overlap_culled_adam="after_binning")
     f = a["steps_scaler"]
     if f != 1.0:        # gsplat Config.adjust_steps
         import dataclasses

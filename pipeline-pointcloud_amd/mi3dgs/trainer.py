@@ -89,7 +89,7 @@ class TrainConfig:
     # fused single-GPU path: the Adam update of the 64-Gaussian groups none of whose members is visible needs no gradient; it is
     # launched on a second stream right after the binning and streams under the rasterisers (which leave HBM idle) instead of
     # after them.  Same update for every Gaussian, exactly once; pays where many groups are culled as a whole, i.e. with the
-    # Gaussians in Morton order (spatial_sort_init).  "after_project" / "after_binning": where the side launch is issued.
+    # Gaussians in Morton order (spatial_sort_init).  "after_project" / "after_binning" / "after_raster_fwd": where the side launch is issued.
     overlap_culled_adam: Optional[str] = None
     # Adam fused into the backward (single-GPU path; the data-parallel trainer needs the
     # gradients for its all-reduce and switches this off)
@@ -304,6 +304,8 @@ class Trainer:
         self._seg_ws = ops.raster_seg_workspace(binning, 1, self.device, self.raster_out) if segments else None
         render, alphas, last_ids = ops.rasterize_fwd(splats, binning, self.W, self.H, 16, background, self.raster_out,
                                                      seg_ws=self._seg_ws)
+        if hooks and "after_raster_fwd" in hooks:
+            hooks["after_raster_fwd"](radii, splats)
         self.last_binning = binning
         return radii, splats, binning, render, alphas, last_ids
 
@@ -337,7 +339,8 @@ class Trainer:
             bg = self._bg_table[k]
         fused = c.fuse_adam and self._can_fuse_adam()
         sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
-        split = fused and c.overlap_culled_adam in ("after_project", "after_binning")
+        # (not in a step that applies the scale regulariser: that one gives culled Gaussians a gradient too)
+        split = fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd") and not sreg
         hooks = None
         if split:
             if self._side_stream is None:
@@ -351,13 +354,9 @@ class Trainer:
                 self._side_stream.wait_event(self._ev_main)
                 with torch.cuda.stream(self._side_stream):
                     bank_ = m.banks[m.cur]
-                    ops.project_bwd_adam([bank_[g]["p"] for g in GROUPS], [bank_[g]["m"] for g in GROUPS],
-                                         [bank_[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, viewmat, K, self.W,
-                                         self.H, radii_, splats_, self.v_splats[:, :n], n=n, sh_degree=sd,
-                                         flags=self._flags() | ops.FLAG_ONLY_CULLED_GROUPS,
-                                         beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
-                                         scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
-                                         scale_reg_max_ratio=c.max_gauss_ratio, stats=None, stat_use_abs=c.absgrad)
+                    ops.adam_culled_groups([bank_[g]["p"] for g in GROUPS], [bank_[g]["m"] for g in GROUPS],
+                                           [bank_[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, radii_, n=n,
+                                           beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps)
                     self._ev_side.record(self._side_stream)
 
             hooks = {c.overlap_culled_adam: culled_groups}

@@ -511,13 +511,53 @@ def test_culled_groups_adam_on_a_second_stream_is_the_same_update(dev):
         torch.cuda.synchronize()
         vis = (tr.radii[0, :6000] > 0).all(-1)
         out.append(({k: tr.model.p(k).clone() for k in trainer.GROUPS}, {k: tr.model.state(k, "m").clone() for k in trainer.GROUPS}, vis))
-    never = ~out[0][2]              # (culled in the last view; the far block is culled in every view)
-    assert 64 * 20 < int(never.sum()) < 6000 - 64 * 20
-    far = torch.zeros(6000, dtype=torch.bool, device=dev)
-    far[:0] = False
+    assert 64 * 20 < int((~out[0][2]).sum()) < 6000 - 64 * 20
     for k in trainer.GROUPS:
         for o in out[1:]:
             assert rel_err(o[0][k], out[0][0][k]) < 2e-3 and rel_err(o[1][k], out[0][1][k]) < 2e-3, k
+
+
+def test_culled_groups_kernel_gives_the_fused_kernels_bits(dev):
+    """mi3dgs_adam_culled_groups against mi3dgs_project_bwd_adam restricted to the same groups (MI3DGS_FLAG_ONLY_CULLED_GROUPS): random
+    parameters and moments, groups of 64 marked culled / visible through the radii -- bit for bit on the culled groups, nothing
+    touched elsewhere; including a last group of fewer than 64 Gaussians."""
+    ops = _ops()
+    from mi3dgs import trainer
+    g = torch.Generator().manual_seed(14)
+    N = 64 * 37 + 23
+    W = dict(zip(trainer.GROUPS, trainer.WIDTHS))
+    lrs = [1.6e-4, 1e-3, 5e-3, 5e-2, 2.5e-3, 1.25e-4]
+    radii = torch.zeros(1, N, 2, dtype=torch.int32)
+    vis_groups = torch.rand(38, generator=g) < 0.5
+    vis_groups[37] = False                                 # the partial last group is culled
+    for gi in range(38):
+        if vis_groups[gi]:
+            radii[0, 64 * gi + int(torch.randint(0, 64, (1,), generator=g)) % max(1, min(64, N - 64 * gi))] = 3      # ONE visible member
+    radii = radii.to(dev)
+    culled = ~vis_groups.repeat_interleave(64)[:N].to(dev)
+
+    def fresh():
+        gg = torch.Generator().manual_seed(15)
+        P = [torch.randn(N, W[k], generator=gg).to(dev) for k in trainer.GROUPS]
+        M = [(0.01 * torch.randn(N, W[k], generator=gg)).to(dev) for k in trainer.GROUPS]
+        V = [(1e-4 * torch.rand(N, W[k], generator=gg)).to(dev) for k in trainer.GROUPS]
+        return P, M, V
+
+    P0, M0, V0 = fresh()
+    P1, M1, V1 = fresh()
+    P2, M2, V2 = fresh()
+    ops.adam_culled_groups(P1, M1, V1, lrs, 7, radii, n=N)
+    vm = torch.eye(4, device=dev)[None].contiguous()
+    K = torch.tensor([[[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]]], device=dev)
+    splats = torch.zeros(1, N, ops.SPLAT_STRIDE, device=dev)
+    v_splats = torch.zeros(1, N, ops.GRAD_STRIDE, device=dev)
+    ops.project_bwd_adam(P2, M2, V2, lrs, 7, vm, K, 64, 48, radii, splats, v_splats, n=N, sh_degree=3,
+                         flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC | ops.FLAG_ONLY_CULLED_GROUPS)
+    assert int(culled.sum()) > 64 * 8 and int((~culled).sum()) > 64 * 8
+    for a, b, z in zip(P1 + M1 + V1, P2 + M2 + V2, P0 + M0 + V0):
+        assert torch.equal(a[culled], b[culled])                 # the two kernels: the same bits
+        assert torch.equal(a[~culled], z[~culled]) and torch.equal(b[~culled], z[~culled])      # the other groups: untouched
+        assert not torch.equal(a[culled], z[culled])
 
 
 def test_morton_ordered_start_trains_the_same_gaussians(dev):
