@@ -403,6 +403,11 @@ def main():
         Px = sc.width * sc.height
         n_isect = int(tr.last["binning"]["n_isect"].item())
         n_vis = int((tr.radii[:, :n] > 0).all(-1).sum().item())
+        # Gaussians in aligned 64-groups with a visible member (what the fused backward + Adam handles when the culled groups'
+        # update runs as a kernel of its own on the second stream: TrainConfig.overlap_culled_adam)
+        vg = (tr.radii[0, : n // 64 * 64] > 0).all(-1).view(-1, 64).any(1)
+        split_adam = bool(getattr(tr, "_overlap_on", False))
+        n_vgrp = (int(vg.sum().item()) * 64 + n % 64) if split_adam else n
         stages, roof, render_roof = {}, None, None
         if shard and world > 1:
             args.no_stage_profile = True      # a step is collective in this mode: rank 0 can not run extra ones alone
@@ -439,7 +444,10 @@ def main():
                 "adam": n * 1652,
                 # fused backward + Adam: read p, m, v (708) and write them (708) for every Gaussian, plus
                 # radii (8) and, for the visible ones, the splat and gradient records (128)
-                "project_bwd_adam": n * (708 + 708 + 8) + n_vis * 128,
+                # (with the culled groups split off: only the Gaussians of groups with a visible member, every radius still read)
+                "project_bwd_adam": n_vgrp * (708 + 708) + n * 8 + n_vis * 128,
+                # the culled groups' Adam on the second stream: p, m, v read and written, every radius read
+                "adam_culled_groups": (n - n_vgrp) * (708 + 708) + n * 8,
             }
             for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 e = dict(ms_per_step=ms / iters, launches_per_step=cnt / iters, us_per_launch=1e3 * ms / cnt)
@@ -564,6 +572,7 @@ def main():
             "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, {what}",
                        "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
                        "parallelism": par, "mode": args.mode, "gaussians_in_morton_order": bool(tr.cfg.spatial_sort_init),
+                       "culled_groups_adam_on_second_stream": split_adam, "gaussians_in_groups_with_a_visible_member": n_vgrp,
                        "xgmi_bytes_per_rank_per_step": tr.xgmi_bytes_per_step() if shard else 0},
             "render_fps": fps, "roofline": roof, "render_roofline": render_roof, "refine": refine,
             "async_errors": async_bits, "cpu_baseline": cpu, "stages": stages,

@@ -228,7 +228,7 @@ extern "C" int mi3dgs_adam_culled_groups(int N, float* const* params, float* con
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     for (int g = 0; g < 6; g++) A.step_size[g] = (float)(lrs[g] / bc1);
     A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); A.zero = 0.f;
-    MI_LAUNCH("adam_culled", adam_culled_groups_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, radii, A);
+    MI_LAUNCH("adam_culled_groups", adam_culled_groups_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, radii, A);
     MI_LAUNCH_CHECK();
     return 0;
 }

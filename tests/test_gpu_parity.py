@@ -504,11 +504,12 @@ def test_culled_groups_adam_on_a_second_stream_is_the_same_update(dev):
     out = []
     for mode in (None, "after_project", "after_binning"):
         cfg = trainer.TrainConfig(max_steps=300, densify=False, sh_degree_interval=1, spatial_sort_init=True, overlap_culled_adam=mode,
-                                  use_scale_regularization=True, scale_reg_every=3)
+                                  overlap_min_gaussians=0, use_scale_regularization=True, scale_reg_every=3)
         tr = trainer.Trainer(P, g.viewmats, g.Ks, imgs, 96, 64, cfg)
         for i in range(12):
             tr.step(i % 4)
         torch.cuda.synchronize()
+        assert bool(tr._overlap_on) == (mode is not None)          # (the two-launch path really ran)
         vis = (tr.radii[0, :6000] > 0).all(-1)
         out.append(({k: tr.model.p(k).clone() for k in trainer.GROUPS}, {k: tr.model.state(k, "m").clone() for k in trainer.GROUPS}, vis))
     assert 64 * 20 < int((~out[0][2]).sum()) < 6000 - 64 * 20
