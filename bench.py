@@ -477,7 +477,7 @@ def main():
                 # separate runs of this command, gfx950 correction applied; tools/profile_round.sh).  NOT measured
                 # in this run: `traffic_source` says so.  Default workload only.
                 k = tag.split("/")[0]
-                return (pmc_tab.get(k) or pmc_tab.get(k + "_wave") or {}).get("hbm_bytes_per_launch")
+                return (pmc_tab.get(k) or pmc_tab.get(k + "_wave") or pmc_tab.get(k + "_mm") or {}).get("hbm_bytes_per_launch")
 
             traffic = offline_traffic(dom)
             common = dict(kernel=dom, traffic=traffic,
