@@ -148,7 +148,14 @@ def main():
         coef = np.linalg.lstsq(A, dur, rcond=None)[0]
         t0 = st[st[:, 0] > 0, 0].min()
         span = (st[ok, 1].max() - t0) / 100.0
-        probe = dict(lib=a.libs[i], blocks_with_work=int(ok.sum()), fit_us=dict(fixed=round(float(coef[0]), 2), per_1000_entries=round(float(coef[1] * 1000), 2)),
+        s0, e0 = (st[ok, 0] - t0) / 100.0, (st[ok, 1] - t0) / 100.0
+        edges = np.linspace(0, span, 17)
+        act = [float((np.minimum(e0, edges[j + 1]) - np.maximum(s0, edges[j])).clip(min=0).sum() / (edges[j + 1] - edges[j])) for j in range(16)]
+        order = np.argsort(s0)
+        probe_extra = dict(sum_block_us=round(float(dur.sum()), 0), ideal_span_us_at_1024_slots=round(float(dur.sum()) / 1024, 1),
+                           active_blocks_per_sixteenth=[int(round(x)) for x in act],
+                           mean_walk_of_first_and_last_quarter_started=[int(ln[order[: len(order) // 4]].mean()), int(ln[order[-len(order) // 4:]].mean())])
+        probe = dict(lib=a.libs[i], blocks_with_work=int(ok.sum()), **probe_extra, fit_us=dict(fixed=round(float(coef[0]), 2), per_1000_entries=round(float(coef[1] * 1000), 2)),
                      duration_us=dict(median=round(float(np.median(dur)), 1), p90=round(float(np.percentile(dur, 90)), 1), max=round(float(dur.max()), 1)),
                      walked_entries=dict(median=int(np.median(ln)), p90=int(np.percentile(ln, 90)), max=int(ln.max())), span_us=round(float(span), 1),
                      short_blocks_median_us=round(float(np.median(dur[ln <= 64])), 1) if (ln <= 64).any() else None)
