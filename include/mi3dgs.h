@@ -133,6 +133,17 @@ int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float* scales, fl
                             float scale_reg_max_ratio, float* stat_grad2d, float* stat_count,
                             float* stat_radii, int stat_use_abs, void* stream);
 
+/* The same for gsplat's MCMC strategy (simple_trainer mcmc / splatfacto-mcmc): its two regularisers -- opacity_reg * mean(sigmoid(o))
+ * + scale_reg * mean(exp(s)), over EVERY Gaussian, every step -- are folded into the fused kernel, so that the step is one launch
+ * instead of backward + mi3dgs_mcmc_regularise + mi3dgs_adam_step.  (No densify statistics: MCMC does not use them.) */
+int mi3dgs_project_bwd_adam_mcmc(int N, float* means, float* quats, float* scales, float* opacities,
+                                 float* sh0, float* shN, int sh_degree, const float* viewmats,
+                                 const float* Ks, int width, int height, float eps2d, int flags,
+                                 const int32_t* radii, const float* splats, const float* v_splats,
+                                 float* const* exp_avg, float* const* exp_avg_sq, const float* lrs,
+                                 int step, float beta1, float beta2, float eps, float mcmc_opacity_reg,
+                                 float mcmc_scale_reg, void* stream);
+
 /* ---- tile binning --------------------------------------------------------------------
  * Replaces gsplat isect_tiles (count + emit + cub radix sort) and isect_offset_encode.
  * Two phases so that the caller may read the intersection count back between them (exact

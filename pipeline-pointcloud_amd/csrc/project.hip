@@ -581,6 +581,7 @@ struct FusedAdam {
     float step_size[6];     // lr / (1 - beta1^t)
     float b1, b2, eps, inv_bc2_sqrt;
     float sreg_weight, sreg_max_ratio;   // scale regulariser of this step, weight 0 = off
+    float mcmc_opacity_reg, mcmc_scale_reg;      // gsplat's MCMC regularisers (every Gaussian, every step), 0 = off
 };
 
 // (experiments build only: flags bit 6 / 7 skip the small groups' / the shN Adam -- timing experiments, WRONG results)
@@ -776,8 +777,17 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
                     }
                 }
             }
-            const float gsm[14] = {G.vmean[0], G.vmean[1], G.vmean[2], vq[0], vq[1], vq[2], vq[3], vs[0], vs[1], vs[2],
-                                   G.vopa, vc0[0], vc0[1], vc0[2]};
+            float gsm[14] = {G.vmean[0], G.vmean[1], G.vmean[2], vq[0], vq[1], vq[2], vq[3], vs[0], vs[1], vs[2],
+                             G.vopa, vc0[0], vc0[1], vc0[2]};
+            if (A.mcmc_opacity_reg != 0.f || A.mcmc_scale_reg != 0.f) {
+                // gsplat MCMC (simple_trainer mcmc / splatfacto-mcmc): loss += opacity_reg mean(sigmoid(o)) + scale_reg mean(exp(s)),
+                // for EVERY Gaussian -- what mi3dgs_mcmc_regularise adds to the stored gradients of the unfused path
+                // (pp[7..9] = log-scales, pp[10] = opacity logit, read above)
+                const float o = sigmoidf(pp[10]);
+                if (has_opa) gsm[10] += A.mcmc_opacity_reg * o * (1.f - o) / (float)N;
+#pragma unroll
+                for (int i = 0; i < 3; i++) gsm[7 + i] += A.mcmc_scale_reg * __expf(pp[7 + i]) / (3.f * (float)N);
+            }
             {
                 int e = 0;
 #pragma unroll
@@ -1029,13 +1039,13 @@ extern "C" int mi3dgs_project_bwd(int C, int N, const float* means, const float*
 // arrays are updated IN PLACE; no gradient is written.  exp_avg / exp_avg_sq / lrs follow the
 // group order means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45] (HOST arrays of 6).
 // scale_reg_weight > 0 adds the splatfacto scale regulariser's gradient for this step.
-extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float* scales, float* opacities, float* sh0,
-                                       float* shN, int sh_degree, const float* viewmats, const float* Ks, int width,
-                                       int height, float eps2d, int flags, const int32_t* radii, const float* splats,
-                                       const float* v_splats, float* const* exp_avg, float* const* exp_avg_sq,
-                                       const float* lrs, int step, float beta1, float beta2, float eps,
-                                       float scale_reg_weight, float scale_reg_max_ratio, float* stat_grad2d,
-                                       float* stat_count, float* stat_radii, int stat_use_abs, void* stream) {
+static int project_bwd_adam_impl(int N, float* means, float* quats, float* scales, float* opacities, float* sh0,
+                                 float* shN, int sh_degree, const float* viewmats, const float* Ks, int width,
+                                 int height, float eps2d, int flags, const int32_t* radii, const float* splats,
+                                 const float* v_splats, float* const* exp_avg, float* const* exp_avg_sq,
+                                 const float* lrs, int step, float beta1, float beta2, float eps,
+                                 float scale_reg_weight, float scale_reg_max_ratio, float mcmc_opacity_reg, float mcmc_scale_reg,
+                                 float* stat_grad2d, float* stat_count, float* stat_radii, int stat_use_abs, void* stream) {
     MI_REQUIRE(N >= 0 && step >= 1, "project_bwd_adam: bad N / step (step is 1-based)");
     MI_REQUIRE(means && quats && scales && sh0 && shN && exp_avg && exp_avg_sq && lrs, "project_bwd_adam: null argument");
     if (N == 0) return 0;
@@ -1052,10 +1062,37 @@ extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float*
     A.sh0 = sh0;
     A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
+    A.mcmc_opacity_reg = mcmc_opacity_reg; A.mcmc_scale_reg = mcmc_scale_reg;
     MI_LAUNCH("project_bwd_adam", (project_bwd1_kernel<true>), dim3(mi_div_up(N, 256)), dim3(256), 0,
               (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
                   eps2d, flags, radii, splats, const_cast<float*>(v_splats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,
                   stat_count, stat_radii, stat_use_abs);
     MI_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mi3dgs_project_bwd_adam(int N, float* means, float* quats, float* scales, float* opacities, float* sh0,
+                                       float* shN, int sh_degree, const float* viewmats, const float* Ks, int width,
+                                       int height, float eps2d, int flags, const int32_t* radii, const float* splats,
+                                       const float* v_splats, float* const* exp_avg, float* const* exp_avg_sq,
+                                       const float* lrs, int step, float beta1, float beta2, float eps,
+                                       float scale_reg_weight, float scale_reg_max_ratio, float* stat_grad2d,
+                                       float* stat_count, float* stat_radii, int stat_use_abs, void* stream) {
+    return project_bwd_adam_impl(N, means, quats, scales, opacities, sh0, shN, sh_degree, viewmats, Ks, width, height, eps2d, flags, radii,
+                                 splats, v_splats, exp_avg, exp_avg_sq, lrs, step, beta1, beta2, eps, scale_reg_weight,
+                                 scale_reg_max_ratio, 0.f, 0.f, stat_grad2d, stat_count, stat_radii, stat_use_abs, stream);
+}
+
+// The same with gsplat's MCMC regularisers folded in (opacity_reg * mean(sigmoid(o)) + scale_reg * mean(exp(s)) over every Gaussian):
+// the MCMC strategy's training step through the fused kernel instead of backward + regulariser + Adam launches.
+extern "C" int mi3dgs_project_bwd_adam_mcmc(int N, float* means, float* quats, float* scales, float* opacities, float* sh0,
+                                            float* shN, int sh_degree, const float* viewmats, const float* Ks, int width,
+                                            int height, float eps2d, int flags, const int32_t* radii, const float* splats,
+                                            const float* v_splats, float* const* exp_avg, float* const* exp_avg_sq,
+                                            const float* lrs, int step, float beta1, float beta2, float eps,
+                                            float mcmc_opacity_reg, float mcmc_scale_reg, void* stream) {
+    MI_REQUIRE(!(flags & (MI_FLAG_ONLY_CULLED_WAVES | MI_FLAG_ONLY_VISIBLE_WAVES)), "project_bwd_adam_mcmc: every Gaussian has a gradient");
+    return project_bwd_adam_impl(N, means, quats, scales, opacities, sh0, shN, sh_degree, viewmats, Ks, width, height, eps2d, flags, radii,
+                                 splats, v_splats, exp_avg, exp_avg_sq, lrs, step, beta1, beta2, eps, 0.f, 1.f, mcmc_opacity_reg,
+                                 mcmc_scale_reg, nullptr, nullptr, nullptr, 0, stream);
 }

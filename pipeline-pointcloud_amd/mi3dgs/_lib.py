@@ -43,6 +43,8 @@ _SIGNATURES = {
     "mi3dgs_project_bwd_adam": (_i, [_i, _f, _f, _f, _f, _f, _f, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
                                      C.POINTER(_f), C.POINTER(_f), C.POINTER(_fl), _i, _fl, _fl, _fl, _fl, _fl,
                                      _f, _f, _f, _i, _f]),
+    "mi3dgs_project_bwd_adam_mcmc": (_i, [_i, _f, _f, _f, _f, _f, _f, _i, _f, _f, _i, _i, _fl, _i, _f, _f, _f,
+                                          C.POINTER(_f), C.POINTER(_f), C.POINTER(_fl), _i, _fl, _fl, _fl, _fl, _fl, _f]),
     "mi3dgs_bin_workspace_bytes": (_sz, [_i, _i, _ll]),
     "mi3dgs_bin_count": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f, _sz, _ll, _f]),
     "mi3dgs_bin_emit": (_i, [_i, _i, _f, _f, _i, _i, _i, _i, _i, _f, _ll, _f, _f, _f, _f, _f, _sz, _f]),

@@ -127,10 +127,11 @@ def project_bwd(means, quats, scales, opacities, viewmats, Ks, width, height, ra
 
 def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, height, radii, splats, v_splats, *,
                      n, sh_degree, eps2d=0.3, flags=0, beta1=0.9, beta2=0.999, eps=1e-15, scale_reg_weight=0.0,
-                     scale_reg_max_ratio=10.0, stats=None, stat_use_abs=False):
+                     scale_reg_max_ratio=10.0, stats=None, stat_use_abs=False, mcmc_opacity_reg=0.0, mcmc_scale_reg=0.0):
     """Single-camera backward with the Adam step fused in: `params` (list of the 6 group
     tensors means, quats, scales, opacities, sh0, shN) are updated in place, no gradients are
-    materialised.  `n` = live Gaussians (the tensors may be larger: capacity)."""
+    materialised.  `n` = live Gaussians (the tensors may be larger: capacity).  mcmc_*: gsplat's MCMC regularisers folded in
+    (mi3dgs_project_bwd_adam_mcmc; no scale_reg_weight / stats with them)."""
     dev = params[0].device
     for t in list(params) + list(exp_avg) + list(exp_avg_sq):
         _chk(t, "parameter / moment buffer")
@@ -138,6 +139,14 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
     if stats is not None:
         sg, sc, sr = stats.get("grad2d"), stats.get("count"), stats.get("radii")
     lr = (C.c_float * 6)(*[float(x) for x in lrs])
+    if mcmc_opacity_reg or mcmc_scale_reg:
+        if scale_reg_weight or stats is not None:
+            raise ValueError("project_bwd_adam: the MCMC regularisers go without scale_reg_weight / stats")
+        _lib.call("mi3dgs_project_bwd_adam_mcmc", int(n), _p(params[0]), _p(params[1]), _p(params[2]), _p(params[3]),
+                  _p(params[4]), _p(params[5]), int(sh_degree), _p(viewmat), _p(K), int(width), int(height), float(eps2d),
+                  int(flags), _p(radii), _p(splats), _p(v_splats), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), lr, int(step),
+                  float(beta1), float(beta2), float(eps), float(mcmc_opacity_reg), float(mcmc_scale_reg), _stream(dev))
+        return
     _lib.call("mi3dgs_project_bwd_adam", int(n), _p(params[0]), _p(params[1]), _p(params[2]), _p(params[3]),
               _p(params[4]), _p(params[5]), int(sh_degree), _p(viewmat), _p(K), int(width), int(height), float(eps2d),
               int(flags), _p(radii), _p(splats), _p(v_splats), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), lr, int(step),

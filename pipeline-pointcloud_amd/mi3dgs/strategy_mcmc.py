@@ -59,7 +59,9 @@ def compute_relocation(opacities: torch.Tensor, scales: torch.Tensor, ratios: to
 class MCMCTrainer(Trainer):
     def __init__(self, params, viewmats, Ks, images, width, height, cfg: Optional[TrainConfig] = None,
                  mcmc: Optional[MCMCConfig] = None):
-        cfg = dataclasses.replace(cfg or TrainConfig(), densify=False, fuse_adam=False)
+        # (the regularisers are folded into the fused backward + Adam: ops.project_bwd_adam(mcmc_*); fuse_adam=False in the config
+        #  keeps the three-launch path -- backward, mi3dgs_mcmc_regularise, Adam -- which the data-parallel trainer needs anyway)
+        cfg = dataclasses.replace(cfg or TrainConfig(), densify=False)
         self.mcmc = mcmc or MCMCConfig()
         if cfg.capacity is None or cfg.capacity < self.mcmc.cap_max:
             cfg = dataclasses.replace(cfg, capacity=max(self.mcmc.cap_max, params["means"].shape[0]))
@@ -69,7 +71,10 @@ class MCMCTrainer(Trainer):
         self.mcmc_totals = dict(relocated=0, added=0)
         self.last_max_ratio = 0
 
-    # gradients of the two regularisers, between the backward and Adam
+    def _fused_regularisers(self):
+        return float(self.mcmc.opacity_reg), float(self.mcmc.scale_reg)
+
+    # gradients of the two regularisers, between the backward and Adam (unfused path)
     def _grad_hooks(self):
         m, c = self.model, self.mcmc
         ops._lib.call("mi3dgs_mcmc_regularise", m.n, ops._p(m.p("opacities")), ops._p(m.p("scales")), float(c.opacity_reg),

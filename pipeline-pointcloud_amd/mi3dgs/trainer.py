@@ -339,10 +339,13 @@ class Trainer:
             if self._bg_table is None or k == 0:
                 self._bg_table = torch.rand(8192, 1, 3, generator=self.dev_gen, device=self.device)
             bg = self._bg_table[k]
-        fused = c.fuse_adam and self._can_fuse_adam()
         sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
+        # (a step that applies BOTH splatfacto's scale regulariser and a strategy's own regularisers takes the unfused launches)
+        fused = c.fuse_adam and self._can_fuse_adam() and not (sreg and any(self._fused_regularisers()))
         # (not in a step that applies the scale regulariser: that one gives culled Gaussians a gradient too)
-        split = fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd") and not sreg and self._overlap_pays()
+        regs = self._fused_regularisers() if fused else (0.0, 0.0)
+        split = (fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd") and not sreg
+                 and not any(regs) and self._overlap_pays())
         hooks = None
         if split:
             if self._side_stream is None:
@@ -380,7 +383,8 @@ class Trainer:
                                  flags=self._flags() | ops.FLAG_CLEAR_VSPLATS | (ops.FLAG_ONLY_VISIBLE_GROUPS if split else 0),
                                  beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
                                  scale_reg_weight=c.scale_reg_weight if sreg else 0.0,
-                                 scale_reg_max_ratio=c.max_gauss_ratio, stats=stats, stat_use_abs=c.absgrad)
+                                 scale_reg_max_ratio=c.max_gauss_ratio, stats=stats, stat_use_abs=c.absgrad,
+                                 mcmc_opacity_reg=regs[0], mcmc_scale_reg=regs[1])
             if split:          # the next step's projection reads every parameter
                 torch.cuda.current_stream(self.device).wait_event(self._ev_side)
         else:
@@ -430,6 +434,10 @@ class Trainer:
 
     def _can_fuse_adam(self) -> bool:
         return True
+
+    def _fused_regularisers(self):
+        """(opacity_reg, scale_reg) of a strategy whose regularisers the fused backward + Adam folds in (MCMC); (0, 0) otherwise."""
+        return 0.0, 0.0
 
     # -- intersection capacity (auto_isect_capacity) -------------------------------------
     def calibrate_isect_capacity(self, margin: float = 2.0) -> int:

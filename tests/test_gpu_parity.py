@@ -858,6 +858,30 @@ def test_mcmc_trainer_relocates_and_grows(dev):
     assert all(torch.isfinite(tr.model.p(k)).all() for k in trainer.GROUPS)
 
 
+def test_mcmc_step_through_the_fused_kernel_equals_the_three_launches(dev):
+    """MCMCTrainer: backward + mi3dgs_mcmc_regularise + Adam (fuse_adam=False) against the one fused launch with the regularisers
+    folded in (mi3dgs_project_bwd_adam_mcmc), including steps that also apply splatfacto's scale regulariser (those take the
+    unfused launches in both runs).  No relocation / noise in these steps (refine_start_iter beyond them, noise_lr 0)."""
+    from mi3dgs import trainer
+    from mi3dgs.strategy_mcmc import MCMCConfig, MCMCTrainer
+    sc = small_scene(n=1500, seed=16, big=True, width=96, height=64, n_views=4, fx=90.0)
+    g = sc.to(dev)
+    imgs = torch.rand(4, 64, 96, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = []
+    for fuse in (False, True):
+        cfg = trainer.TrainConfig(max_steps=300, sh_degree_interval=1, fuse_adam=fuse, use_scale_regularization=True, scale_reg_every=4)
+        mc = MCMCConfig(cap_max=2000, refine_start_iter=10_000, noise_lr=0.0, opacity_reg=0.01, scale_reg=0.01)
+        tr = MCMCTrainer(g.params, g.viewmats, g.Ks, imgs, 96, 64, cfg, mc)
+        for i in range(10):
+            tr.step(i % 4)
+        torch.cuda.synchronize()
+        out.append(({k: tr.model.p(k)[: tr.model.n].clone() for k in trainer.GROUPS}, {k: tr.model.state(k, "m").clone() for k in trainer.GROUPS}))
+    for k in trainer.GROUPS:
+        assert rel_err(out[1][0][k], out[0][0][k]) < 2e-3 and rel_err(out[1][1][k], out[0][1][k]) < 2e-3, k
+    # the regularisers reach Gaussians no view sees: their opacities and scales move identically in both runs
+    assert not torch.equal(out[1][0]["opacities"], g.params["opacities"].reshape(out[1][0]["opacities"].shape))
+
+
 def test_mcmc_regulariser_gradients_match_autograd(dev):
     """loss += opacity_reg * mean(sigmoid(o)) + scale_reg * mean(exp(s))  (gsplat simple_trainer, mcmc preset):
     the kernel ADDS exactly that gradient to what the backward left, with the 1/N and 1/(3N) of the two means."""
