@@ -262,6 +262,14 @@ int mi3dgs_rasterize_bwd(int C, int width, int height, int tile_size, int tile_w
  * (csrc/rasterize.hip). */
 int mi3dgs_debug_set_raster_mode(int mode);
 
+/* Process-wide.  0 (default): mi3dgs_rasterize_fwd walks every tile's list serially (and, given a segment workspace, leaves the
+ * backward's checkpoints).  1: given a segment workspace it walks the lists of more than 256 entries as segments of 256 side by
+ * side (four launches: plan; segments + short tiles; combine; the segments pixels stop in, once more).  Results agree to float
+ * rounding (T_in * prod(1 - alpha) is associated differently; a pixel whose transmittance comes within an ulp of the 1e-4 stop may
+ * end one segment early: bounded by 1e-4 in colour).  Halves the forward where lists are walked to their ends; slower where the
+ * pixels saturate early, which is most of training.  The backward is the same either way. */
+int mi3dgs_debug_set_raster_fwd_segments(int on);
+
 /* ---- loss ----------------------------------------------------------------------------
  * Replaces the L1 + SSIM(11x11, sigma 1.5) loss of splatfacto / simple_trainer.
  * sums[2] (zeroed by the caller; nullable when the loss VALUE of the step is not wanted) receives

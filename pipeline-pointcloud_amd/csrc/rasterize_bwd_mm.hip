@@ -315,6 +315,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     if (worker) {
         const uint4 wk = seg.work[item];
         t = (int)wk.x; seg_lo = (int)wk.y; slot_ck = wk.z; seg_len = (int)wk.w;
+        if (seg_len == 0) return;          // a forward segment whose end boundary no pixel walked past: nothing for the backward
     }
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
             if (__hip_atomic_fetch_add(&seg.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)n_workers - 1u) {
                 __hip_atomic_store(&seg.ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&seg.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&seg.ctl[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -606,11 +608,11 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
                         const float* v_alphas, int absgrad, float* v_splats, int experiment, const float* render, void* seg_ws,
                         size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
-    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    SegWs seg = {};
     if (seg_ws) {
         MI_REQUIRE(render != nullptr, "rasterize_bwd: the segment workspace needs the forward's render too");
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_bwd: segment workspace too small");
-        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};      // as the forward decided
+        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{};      // as the forward decided
     }
     const int n_workers = seg.ckpt ? SEG_WORKERS : 0;
     const int grid = raster_grid(n_tiles, tile_width) + n_workers;

@@ -260,16 +260,30 @@ struct PixelBasis { float u, v, uu, uv, vv; };
 // of at least 4 096 tiles, both rasterisers ignore the workspace (seg_ws_in_use) and run as if none had been given.
 constexpr int SEG_MIN = 256;              // = BLOCK: the forward can only stop at its batch boundaries
 struct SegWs {
-    uint32_t* ctl;        // [0] work items handed out
+    uint32_t* ctl;        // [0] work items handed out, [1] backward workers that have read it, [2] heavy tiles (forward in segments)
     uint32_t* tile_skip;  // [n_tiles] entries at the head of each tile's list that belong to work items (its own block starts behind them)
+    uint32_t* heavy;      // [n_tiles] forward in segments: the tiles whose lists are walked as segments
+    uint2* tile_items;    // [n_tiles] forward in segments: {first item, segments} of a heavy tile
     uint4* work;          // [cap] {tile, first list entry of the segment, checkpoint slot of its END boundary, entries in the segment}
+                          //       (entries = 0: a segment of the FORWARD whose end boundary no pixel walked past -- no backward item)
     float4* ckpt;         // [cap][256] T, r, g, b per pixel (thread order of the forward block) at the boundary
+    int32_t* local_last;  // [cap][256] forward in segments: last contributor inside the segment (0x3fffffff: none) | bit 30: stopped inside
     uint32_t cap;
     uint32_t seg;         // entries per segment of this call (forward only)
 };
+constexpr size_t SEG_ITEM_BYTES = 16 + BLOCK * 16 + BLOCK * 4;
+inline size_t seg_ws_fixed(int n_tiles) {
+    const size_t a4 = ((size_t)n_tiles * 4 + 255) & ~(size_t)255, a8 = ((size_t)n_tiles * 8 + 255) & ~(size_t)255;
+    return 256 + 2 * a4 + a8 + 512;
+}
+inline size_t seg_ws_cap(int n_tiles, size_t bytes) {
+    const size_t fixed = seg_ws_fixed(n_tiles);
+    return bytes < fixed + SEG_ITEM_BYTES ? 0 : (bytes - fixed) / SEG_ITEM_BYTES;
+}
 inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
-    const size_t cap = (size_t)(max_isect / SEG_MIN) + 16;       // a boundary has >= SEG_MIN entries of its tile in front of it
-    return 512 + (((size_t)n_tiles * 4 + 255) & ~(size_t)255) + cap * (16 + BLOCK * 16);
+    // a backward item has >= SEG_MIN entries of its tile in front of its boundary; a heavy tile's last forward segment may be short
+    const size_t cap = (size_t)(max_isect / SEG_MIN) + (size_t)n_tiles + 16;
+    return seg_ws_fixed(n_tiles) + cap * SEG_ITEM_BYTES;
 }
 // The workspace is not used where lists are long everywhere AND there are tiles enough to fill the device many times over
 // (S2, S3: nothing to balance).  Few tiles with long lists are the opposite case: the first 3 000 steps of an ns-train run render
@@ -277,23 +291,28 @@ inline size_t seg_ws_bytes_for(int n_tiles, long long max_isect) {
 constexpr size_t SEG_OFF_ENTRIES_PER_TILE = 1024;
 constexpr int SEG_OFF_MIN_TILES = 4096;
 inline bool seg_ws_in_use(int n_tiles, size_t bytes) {
-    const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255, fixed = 512 + nb_bytes;
-    if (bytes < fixed + (16 + BLOCK * 16)) return false;
-    const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
-    const bool long_everywhere = (cap > 16 ? cap - 16 : 0) * SEG_MIN / (size_t)(n_tiles > 0 ? n_tiles : 1) > SEG_OFF_ENTRIES_PER_TILE;
+    const size_t cap = seg_ws_cap(n_tiles, bytes);
+    if (cap == 0) return false;
+    const size_t nt = (size_t)(n_tiles > 0 ? n_tiles : 1);
+    const size_t est_isect = cap > nt + 16 ? (cap - nt - 16) * SEG_MIN : 0;
+    const bool long_everywhere = est_isect / nt > SEG_OFF_ENTRIES_PER_TILE;
     return !(long_everywhere && n_tiles >= SEG_OFF_MIN_TILES);
 }
 // both rasterisers derive the same views from (n_tiles, bytes)
 inline bool seg_ws_layout(int n_tiles, void* base, size_t bytes, SegWs* out) {
-    const size_t nb_bytes = ((size_t)n_tiles * 4 + 255) & ~(size_t)255;
-    const size_t fixed = 512 + nb_bytes;
-    if (bytes < fixed + (16 + BLOCK * 16)) return false;
-    const size_t cap = (bytes - fixed) / (16 + BLOCK * 16);
+    const size_t cap = seg_ws_cap(n_tiles, bytes);
+    if (cap == 0) return false;
+    const size_t a4 = ((size_t)n_tiles * 4 + 255) & ~(size_t)255, a8 = ((size_t)n_tiles * 8 + 255) & ~(size_t)255;
     char* b = (char*)base;
     out->ctl = (uint32_t*)b;
     out->tile_skip = (uint32_t*)(b + 256);
-    out->work = (uint4*)(b + 256 + nb_bytes);
-    out->ckpt = (float4*)(b + 256 + nb_bytes + ((cap * 16 + 255) & ~(size_t)255));
+    out->heavy = (uint32_t*)(b + 256 + a4);
+    out->tile_items = (uint2*)(b + 256 + 2 * a4);
+    char* w = b + 256 + 2 * a4 + a8;
+    out->work = (uint4*)w;
+    char* c = w + ((cap * 16 + 255) & ~(size_t)255);
+    out->ckpt = (float4*)c;
+    out->local_last = (int32_t*)(c + cap * BLOCK * 16);
     out->cap = (uint32_t)cap;
     out->seg = SEG_MIN;
     return true;

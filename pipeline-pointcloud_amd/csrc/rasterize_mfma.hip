@@ -129,6 +129,321 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     if (seg.ckpt != nullptr && threadIdx.x == 0) seg.tile_skip[t] = nb * seg.seg;
 }
 
+// ---------------------------------------------------------------------------------------- forward in segments
+// One block per tile walks the tile's list serially: a launch lasts as long as its heaviest tile.  On a dense object-centric scene
+// (gsplat's MCMC strategy at its cap of 1 M Gaussians, 960 x 720: 2.3 M intersections, a tenth of the tiles with 2 500 - 5 200 entries,
+// every one of them reached) rasterize_fwd took 555 us of a 1.9 ms step for work that fills the device for a fifth of that time.
+// With the segment workspace the heavy tiles are walked as segments of 256 entries side by side:
+//   fwd_plan_kernel             a thread per tile: a tile of more than 256 entries books one work item per 256 entries;
+//   rasterize_fwd_seg_kernel    the first blocks of the grid are segment workers: every segment from T = 1, C = 0: its transmittance
+//                               product P, its colour C, its last contributor, and whether a pixel ran into the transmittance stop
+//                               inside it; the other blocks are the tiles of at most 256 entries, walked as always;
+//   fwd_combine_kernel          per heavy tile and pixel, segment after segment: T_in P > 1e-4 and no stop inside -> the segment is
+//                               taken whole (C += T_in C_s, T_in *= P); otherwise the pixel stops inside THAT segment: its state
+//                               at the segment's start is left in the segment's slot.  Also leaves the backward's checkpoints
+//                               at the boundaries pixels walked past;
+//   fwd_finish_kernel           the segments pixels stop in, walked again for those pixels from their true state, entry by entry
+//                               as the serial forward does; all of them side by side (strung behind one another in the combine
+//                               pass they took 298 us of a 487 us forward).
+// Same result as the serial walk up to the rounding of T_in * (local product) against the running product.
+
+// the serial forward's walk over entries [lo, hi) for the block's pixels
+__device__ __forceinline__ void fwd_walk_range(Staged& L, const float* __restrict__ splats, const int32_t* __restrict__ flatten_ids, int lo,
+                                               int hi, float xc, float yc, int lane, const Basis& basis, float& T, float& cr, float& cg,
+                                               float& cb, int& cur, unsigned long long& live) {
+    for (int bs = lo; bs < hi; bs += BLOCK) {
+        if (!__syncthreads_or(live != 0ull)) break;
+        {
+            const int i1 = bs + (int)threadIdx.x;
+            stage_splat(L, (int)threadIdx.x, load_rec(splats, i1 < hi ? flatten_ids[i1] : -1), xc, yc);
+        }
+        __syncthreads();
+        const int bsz = min(BLOCK, hi - bs);
+        for (int sb = 0; sb * SUB < bsz; sb++) {
+            if (live == 0ull) break;
+            float s[SUB];
+            eval_sub_batch(L, sb, lane, basis, s);
+            const lds_f4_ptr uni = opaque_lds_base(&L.uni[sb * SUB]);
+            Rgb col_next = lds_rgb(uni, 0);
+#pragma unroll
+            for (int i = 0; i < SUB; i++) {
+                if ((i & 7) == 0 && i > 0 && live == 0ull) break;
+                const Rgb col = col_next;
+                col_next = lds_rgb(uni, i + 1);
+                const unsigned long long hit = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & live;
+                if (hit == 0ull) continue;
+                const float alpha = alpha_of(s[i]);
+                const float wgt = alpha * T;
+                const float nT = T - wgt;
+                const unsigned long long comp = mask_gt(nT, T_STOP) & hit;
+                live &= ~(hit & ~comp);
+                if (lane_of(comp)) {
+                    cr = __builtin_fmaf(col.x, wgt, cr);
+                    cg = __builtin_fmaf(col.y, wgt, cg);
+                    cb = __builtin_fmaf(col.z, wgt, cb);
+                    cur = bs + sb * SUB + i;
+                    T = nT;
+                }
+            }
+        }
+    }
+}
+
+struct TileGeom { int cam, tx, ty, px_i, py_i; bool inside; float xc, yc; };
+__device__ __forceinline__ TileGeom tile_geom(int t, int tw, int th, int W, int H, int wv, int lane) {
+    TileGeom g;
+    g.cam = t / (tw * th);
+    const int tile_in = t - g.cam * (tw * th);
+    g.ty = tile_in / tw; g.tx = tile_in - g.ty * tw;
+    int lx, ly;
+    pixel_of_lane(wv, lane, lx, ly);
+    g.px_i = g.tx * TILE + lx; g.py_i = g.ty * TILE + ly;
+    g.inside = g.px_i < W && g.py_i < H;
+    g.xc = (float)(g.tx * TILE) + 8.f; g.yc = (float)(g.ty * TILE) + 8.f;
+    return g;
+}
+
+#ifdef MI3DGS_OS_STAMPS
+// Probe build only (tools/fwd_seg_probe.py): per block of rasterize_fwd_seg_kernel start / end wall-clock stamps (100 MHz), entries walked.
+__device__ unsigned long long g_rf_stamps[8192][3];
+#define RF_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_rf_stamps[blockIdx.x][i] = (v); } while (0)
+}  // namespace mfma_raster
+extern "C" int mi3dgs_debug_read_rf_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfma_raster::g_rf_stamps), bytes < sizeof(mfma_raster::g_rf_stamps) ? bytes : sizeof(mfma_raster::g_rf_stamps));
+}
+namespace mfma_raster {
+#else
+#define RF_STAMP(i, v) do { } while (0)
+#endif
+
+constexpr int FWD_SEG_WORKERS = 2048;
+constexpr int SEG_NONE = 0x3fffffff, SEG_STOPPED = 0x40000000;
+
+// One block: slots in tile order by a prefix sum, the two counters WRITTEN (a forward with no backward behind it -- an evaluation
+// render -- leaves nothing for the next forward to trip over).
+__global__ __launch_bounds__(1024) void fwd_plan_kernel(const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ n_isect_ptr,
+                                                        int n_tiles_total, SegWs seg) {
+    __shared__ unsigned long long s_wave[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long run = 0ull;                                   // low word: segments booked so far, high word: heavy tiles
+    for (int t0 = 0; t0 < n_tiles_total; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        uint32_t n_seg = 0u;
+        int start = 0;
+        if (t < n_tiles_total) {
+            start = tile_offsets[t];
+            const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+            if (end - start > SEG_MIN) n_seg = (uint32_t)((end - start + SEG_MIN - 1) / SEG_MIN);
+        }
+        const unsigned long long mine = n_seg ? ((1ull << 32) | n_seg) : 0ull;
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        unsigned long long before = run, total = 0ull;
+        for (int w = 0; w < 16; w++) {
+            const unsigned long long v = s_wave[w];
+            if (w < wv) before += v;
+            total += v;
+        }
+        if (n_seg) {
+            const unsigned long long at = before + incl - mine;
+            const uint32_t base = (uint32_t)at, hv = (uint32_t)(at >> 32);
+            // a segment's item carries 0 entries until the combine pass has seen a pixel walk past its end boundary (the backward
+            // skips those); base + n_seg <= cap: the capacity counts every segment of every tile
+            for (uint32_t k = 0; k < n_seg; k++) seg.work[base + k] = make_uint4((uint32_t)t, (uint32_t)start + k * SEG_MIN, base + k, 0u);
+            seg.tile_items[t] = make_uint2(base, n_seg);
+            seg.heavy[hv] = (uint32_t)t;
+        }
+        run += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { seg.ctl[0] = (uint32_t)run; seg.ctl[2] = (uint32_t)(run >> 32); }
+}
+
+template <bool HAS_BG>
+__global__ __launch_bounds__(BLOCK) void rasterize_fwd_seg_kernel(int W, int H, int tw, int th, const float* __restrict__ splats,
+                                                                  const int32_t* __restrict__ tile_offsets,
+                                                                  const int32_t* __restrict__ flatten_ids,
+                                                                  const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+                                                                  const float* __restrict__ backgrounds, float* __restrict__ render,
+                                                                  float* __restrict__ alphas, int32_t* __restrict__ last_ids, int bands,
+                                                                  int n_workers, SegWs seg) {
+    __shared__ Staged L;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const Basis basis = make_basis(wv, lane);
+    RF_STAMP(0, wall_clock64()); RF_STAMP(1, 0ull); RF_STAMP(2, 0ull);
+    if ((int)blockIdx.x < n_workers) {
+        const int n_items = (int)min(seg.ctl[0], seg.cap);
+        for (int item = blockIdx.x; item < n_items; item += n_workers) {
+            const uint4 wk = seg.work[item];
+            const int t = (int)wk.x, lo = (int)wk.y;
+            const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+            const int hi = min(lo + SEG_MIN, end);
+            const TileGeom g = tile_geom(t, tw, th, W, H, wv, lane);
+            float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+            int cur = -1;
+            const unsigned long long live0 = wave_ballot(g.inside);
+            unsigned long long live = live0;
+            __syncthreads();                                   // the walk before may still be reading L
+            fwd_walk_range(L, splats, flatten_ids, lo, hi, g.xc, g.yc, lane, basis, T, cr, cg, cb, cur, live);
+            const bool stopped = ((live0 & ~live) >> lane) & 1ull;
+            seg.ckpt[(size_t)wk.z * BLOCK + threadIdx.x] = make_float4(T, cr, cg, cb);
+            seg.local_last[(size_t)wk.z * BLOCK + threadIdx.x] = (cur < 0 ? SEG_NONE : cur) | (stopped ? SEG_STOPPED : 0);
+            RF_STAMP(2, (unsigned long long)(hi - lo));
+        }
+        RF_STAMP(1, wall_clock64());
+        return;
+    }
+    const int t = tile_of_block((int)blockIdx.x - n_workers, n_tiles_total, bands, tw);
+    if (t < 0) return;
+    const int start = tile_offsets[t];
+    const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+    if (end - start > SEG_MIN) return;                         // in segments: the workers and the combine pass
+    const TileGeom g = tile_geom(t, tw, th, W, H, wv, lane);
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    int cur = 0;
+    unsigned long long live = wave_ballot(g.inside);
+    fwd_walk_range(L, splats, flatten_ids, start, end, g.xc, g.yc, lane, basis, T, cr, cg, cb, cur, live);
+    if (g.inside) {
+        const size_t pix = ((size_t)g.cam * H + g.py_i) * W + g.px_i;
+        if (HAS_BG) {
+            const float* bg = backgrounds + 3 * g.cam;
+            cr += T * bg[0]; cg += T * bg[1]; cb += T * bg[2];
+        }
+        render[3 * pix] = cr; render[3 * pix + 1] = cg; render[3 * pix + 2] = cb;
+        alphas[pix] = 1.f - T;
+        last_ids[pix] = cur;
+    }
+    if (threadIdx.x == 0) seg.tile_skip[t] = 0u;
+    RF_STAMP(1, wall_clock64()); RF_STAMP(2, (unsigned long long)(end - start));
+}
+
+constexpr int SEG_PENDING = (int)0x80000000;
+
+// No walking here: a thread per pixel strings the segments' results together.  A pixel that can not take a segment whole (it stops
+// inside it) leaves its state at the segment's start in the segment's own slot and is finished here: fwd_finish_kernel walks
+// that segment for it.
+template <bool HAS_BG>
+__global__ __launch_bounds__(BLOCK) void fwd_combine_kernel(int W, int H, int tw, int th, const float* __restrict__ backgrounds,
+                                                            float* __restrict__ render, float* __restrict__ alphas,
+                                                            int32_t* __restrict__ last_ids, SegWs seg) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int n_heavy = (int)seg.ctl[2];
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int t = (int)seg.heavy[h];
+        const uint2 ti = seg.tile_items[t];
+        const TileGeom g = tile_geom(t, tw, th, W, H, wv, lane);
+        float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        int cur = 0;
+        bool mine = g.inside, pending = false;
+        uint32_t nb = 0;
+        // The per-segment results are fetched PF segments ahead (a dependent chain of global loads, one per segment, was 2.5 us a
+        // segment); per segment one barrier carries one block-wide fact: somebody is still compositing here.
+        constexpr int PF = 8;
+        bool go = true;
+        for (uint32_t k = 0; go && k < ti.y; k += PF) {
+            float4 lc[PF];
+            int enc[PF];
+#pragma unroll
+            for (int j = 0; j < PF; j++)
+                if (k + j < ti.y) {
+                    lc[j] = seg.ckpt[(size_t)(ti.x + k + j) * BLOCK + threadIdx.x];
+                    enc[j] = seg.local_last[(size_t)(ti.x + k + j) * BLOCK + threadIdx.x];
+                }
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                if (go && k + j < ti.y) {
+                    const uint32_t kk = k + j, slot = ti.x + kk;
+                    const int f = __syncthreads_or(mine);
+                    if (!f) {
+                        go = false;
+                    } else {
+                        if (kk > 0) {
+                            // somebody composites on beyond the boundary in front of this segment: the backward's checkpoint (for
+                            // the pixels that do: the backward reads no other) and work item for the segment before
+                            if (mine) seg.ckpt[(size_t)(slot - 1) * BLOCK + threadIdx.x] = make_float4(T, cr, cg, cb);
+                            if (threadIdx.x == 0) seg.work[slot - 1].w = (uint32_t)SEG_MIN;
+                            nb++;
+                        }
+                        if (mine) {
+                            // take the segment whole: the pixel does not stop inside it (the running product only falls: its value
+                            // behind the segment bounds every value inside)
+                            // (the tile's first segment was walked from the pixel's true state, T = 1: taken as it is, stop or no stop)
+                            const bool stopped = (enc[j] & SEG_STOPPED) != 0;
+                            if (kk == 0 || (!stopped && T * lc[j].x > T_STOP)) {
+                                cr = __builtin_fmaf(T, lc[j].y, cr); cg = __builtin_fmaf(T, lc[j].z, cg); cb = __builtin_fmaf(T, lc[j].w, cb);
+                                T *= lc[j].x;
+                                if ((enc[j] & SEG_NONE) != SEG_NONE) cur = enc[j] & SEG_NONE;
+                                if (stopped) mine = false;
+                            } else {
+                                seg.ckpt[(size_t)slot * BLOCK + threadIdx.x] = make_float4(T, cr, cg, cb);
+                                seg.local_last[(size_t)slot * BLOCK + threadIdx.x] = cur | SEG_PENDING;
+                                mine = false; pending = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (g.inside && !pending) {
+            const size_t pix = ((size_t)g.cam * H + g.py_i) * W + g.px_i;
+            if (HAS_BG) {
+                const float* bg = backgrounds + 3 * g.cam;
+                cr += T * bg[0]; cg += T * bg[1]; cb += T * bg[2];
+            }
+            render[3 * pix] = cr; render[3 * pix + 1] = cg; render[3 * pix + 2] = cb;
+            alphas[pix] = 1.f - T;
+            last_ids[pix] = cur;
+        }
+        if (threadIdx.x == 0) seg.tile_skip[t] = nb * SEG_MIN;
+    }
+}
+
+// The segments some pixel stops in, walked for those pixels from their true state at the segment's start, entry by entry as the
+// serial forward does -- all such segments side by side.  (A pixel that by rounding does NOT stop in this walk -- its T_in P was
+// within an ulp of 1e-4 -- ends here all the same: what it leaves out is bounded by T = 1e-4.)
+template <bool HAS_BG>
+__global__ __launch_bounds__(BLOCK) void fwd_finish_kernel(int W, int H, int tw, int th, const float* __restrict__ splats,
+                                                           const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                                                           const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
+                                                           const float* __restrict__ backgrounds, float* __restrict__ render,
+                                                           float* __restrict__ alphas, int32_t* __restrict__ last_ids, SegWs seg) {
+    __shared__ Staged L;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const Basis basis = make_basis(wv, lane);
+    const int n_items = (int)min(seg.ctl[0], seg.cap);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint4 wk = seg.work[item];
+        const int enc = seg.local_last[(size_t)wk.z * BLOCK + threadIdx.x];
+        const bool pending = enc < 0;
+        if (!__syncthreads_or(pending)) continue;          // (also: the walk before has finished reading L)
+        const int t = (int)wk.x, lo = (int)wk.y;
+        const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
+        const int hi = min(lo + SEG_MIN, end);
+        const TileGeom g = tile_geom(t, tw, th, W, H, wv, lane);
+        const float4 ck = seg.ckpt[(size_t)wk.z * BLOCK + threadIdx.x];
+        float T = ck.x, cr = ck.y, cg = ck.z, cb = ck.w;
+        int cur = enc & SEG_NONE;
+        unsigned long long live = wave_ballot(pending);
+        fwd_walk_range(L, splats, flatten_ids, lo, hi, g.xc, g.yc, lane, basis, T, cr, cg, cb, cur, live);
+        if (pending) {
+            const size_t pix = ((size_t)g.cam * H + g.py_i) * W + g.px_i;
+            if (HAS_BG) {
+                const float* bg = backgrounds + 3 * g.cam;
+                cr += T * bg[0]; cg += T * bg[1]; cb += T * bg[2];
+            }
+            render[3 * pix] = cr; render[3 * pix + 1] = cg; render[3 * pix + 2] = cb;
+            alphas[pix] = 1.f - T;
+            last_ids[pix] = cur;
+        }
+    }
+}
+
 #ifdef MI3DGS_EXPERIMENTS
 // ---------------------------------------------------------------------------------------- backward (cross-lane reduce-scatter)
 struct StagedBwd {
@@ -339,16 +654,41 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
 
 }  // namespace mfma_raster
 
+// 1: with a segment workspace the forward walks tiles of more than 256 entries as segments side by side.  Off unless asked for:
+// the serial walk stops where a tile's pixels are saturated, the segments are all walked before anybody knows where that is.
+// Measured (profiles/r03_fwd_segments.txt): lists walked to their ends (MCMC at its cap after refinement has stopped, 1.9 M
+// intersections on 2 700 tiles) 555 -> 283 us; the same model while it trains -4 .. -10 % of the step rate, default strategy -11 %.
+int g_fwd_segments = 0;
+extern "C" int mi3dgs_debug_set_raster_fwd_segments(int on) {
+    g_fwd_segments = on ? 1 : 0;
+    return 0;
+}
 int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, int tile_height, const float* splats,
                           const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                           const float* backgrounds, float* render, float* alphas, int32_t* last_ids, void* seg_ws, size_t seg_ws_bytes,
                           hipStream_t st) {
     using namespace mfma_raster;
-    SegWs seg = {nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    SegWs seg = {};
     if (seg_ws) {
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_fwd: segment workspace too small (mi3dgs_raster_seg_workspace_bytes)");
         // (the work counter is clear: mi3dgs_raster_seg_workspace_init once, and every backward leaves it clear again)
-        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+        if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{};
+    }
+    if (seg.ckpt != nullptr && g_fwd_segments) {
+        const int n_workers = (int)min((size_t)FWD_SEG_WORKERS, (size_t)seg.cap);
+        MI_LAUNCH("rasterize_fwd_plan", fwd_plan_kernel, dim3(1), dim3(1024), 0, st, isect_offsets, n_isect_dev, n_tiles, seg);
+#define LAUNCH_SEG(BG)                                                                                                    \
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_seg_kernel<BG>), dim3(n_workers + raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width,        \
+              height, tile_width, tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, \
+              raster_bands(), n_workers, seg);                                                                               \
+    MI_LAUNCH("rasterize_fwd_combine", fwd_combine_kernel<BG>, dim3(512), dim3(BLOCK), 0, st, width, height, tile_width, tile_height,           \
+              backgrounds, render, alphas, last_ids, seg);                                                                   \
+    MI_LAUNCH("rasterize_fwd_finish", fwd_finish_kernel<BG>, dim3(n_workers), dim3(BLOCK), 0, st, width, height, tile_width, tile_height, splats, \
+              isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, seg)
+        if (backgrounds) { LAUNCH_SEG(true); } else { LAUNCH_SEG(false); }
+#undef LAUNCH_SEG
+        MI_LAUNCH_CHECK();
+        return 0;
     }
 #define LAUNCH_FWD(BG)                                                                                                    \
     MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \

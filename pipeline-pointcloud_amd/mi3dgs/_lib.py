@@ -53,6 +53,7 @@ _SIGNATURES = {
     "mi3dgs_sort_pairs_u32": (_i, [_f, _f, _ll, _i, _f, _sz, _f]),
     "mi3dgs_debug_set_sort_mode": (_i, [_i]),
     "mi3dgs_debug_set_raster_mode": (_i, [_i]),
+    "mi3dgs_debug_set_raster_fwd_segments": (_i, [_i]),
     "mi3dgs_debug_set_emit_mode": (_i, [_i]),
     "mi3dgs_async_errors": (_i, [C.POINTER(_u32), _i]),
     "mi3dgs_scan_workspace_bytes": (_sz, [_ll]),

@@ -181,6 +181,9 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     ds = ds_mod.load_colmap_dataset(data_dir, downscale, frame=frame)
     if callable(cfg):
         cfg = cfg(ds)
+    if os.environ.get("MI3DGS_FWD_SEGMENTS") == "1":          # A/B of the forward in segments
+        import dataclasses
+        cfg = dataclasses.replace(cfg, raster_fwd_segments=True)
     n_pts = ds.points.shape[0]
     say(f"dataset: {len(ds.train_idx)} train / {len(ds.eval_idx)} eval images {ds.width}x{ds.height}, {n_pts} SfM points")
     params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb, init_opacity=init_opacity, init_scale=init_scale)
@@ -258,6 +261,20 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
                 f"max scale quantiles {[round(float(q), 4) for q in torch.quantile(sc[:1_000_000], torch.tensor([0.5, 0.9, 0.99, 1.0], device=op.device))]}")
     if rank == 0:
         say(f"trained in {train_s:.1f}s = {stats['iters_per_sec']:.1f} it/s, {tr.model.n} Gaussians")
+        if os.environ.get("MI3DGS_LIST_STATS"):          # the last step's tile lists: how long, and how far the pixels walked them
+            b, ro = tr.last_binning, tr.raster_out
+            I = int(b["n_isect"].item())
+            offs = b["isect_offsets"].flatten().long()
+            ln = torch.diff(torch.cat([offs, offs.new_tensor([I])]))
+            th, tw = b["isect_offsets"].shape[-2:]
+            last = ro["last_ids"][0].long()
+            hit = ro["alphas"][0, ..., 0] > 0
+            start = b["isect_offsets"][0].long().repeat_interleave(16, 0).repeat_interleave(16, 1)[: last.shape[0], : last.shape[1]]
+            walked = torch.where(hit, last - start + 1, torch.zeros_like(last))
+            wt = torch.nn.functional.max_pool2d(walked[None, None].float(), 16, ceil_mode=True)[0, 0].flatten()
+            q = lambda t, f: int(torch.quantile(t.float(), f).item())      # noqa: E731
+            say(f"tile lists: {I} intersections on {ln.numel()} tiles; length median {q(ln, .5)} p90 {q(ln, .9)} p99 {q(ln, .99)} max {int(ln.max())}; "
+                f"walked (deepest pixel of a tile) median {q(wt, .5)} p90 {q(wt, .9)} p99 {q(wt, .99)} max {int(wt.max())}")
     return tr, ds, stats
 
 

@@ -233,6 +233,12 @@ def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional
     return out
 
 
+def set_raster_fwd_segments(on: bool) -> None:
+    """Process-wide: with a segment workspace, rasterize_fwd walks tile lists of more than 256 entries as segments side by
+    side (on, the default) or serially, leaving checkpoints for the backward only (off)."""
+    _lib.call("mi3dgs_debug_set_raster_fwd_segments", int(bool(on)))
+
+
 def raster_seg_workspace(binning, Cn, device, out=None):
     """The workspace through which rasterize_fwd hands per-pixel checkpoints to rasterize_bwd (include/mi3dgs.h, "Segment
     workspace"): 4 KB per possible 512-entry boundary, touched only where a tile's list really is that long."""

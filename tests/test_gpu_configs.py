@@ -374,6 +374,63 @@ def test_backward_in_segments_agrees_with_the_serial_walk_at_full_size(dev, kind
     assert ops._lib.async_errors() == 0
 
 
+def _wolf_frame(dev, opacity_scale):
+    """The real-training regime of DESIGN.md 4.2: the reference's wolf.spz inside an opaque shell, 960 x 720 (tools/train_wolf.py)."""
+    import math
+    from helpers import load_wolf
+    from mi3dgs import scenes
+    P = load_wolf()
+    centre = P["means"].median(0).values
+    ext = float((P["means"] - centre).abs().quantile(0.99))
+    W, H = 960, 720
+    P = scenes.add_backdrop(scenes.Scene("wolf", P, None, None, W, H), 12000, 9.0 * ext, tuple(centre.tolist())).params
+    eye = centre + torch.tensor([3.2 * ext * math.cos(0.6) * math.cos(0.3), -3.2 * ext * math.sin(0.3), 3.2 * ext * math.sin(0.6) * math.cos(0.3)])
+    if opacity_scale != 1.0:
+        P["opacities"] = torch.logit((torch.sigmoid(P["opacities"]) * opacity_scale).clamp(1e-4, 0.999))
+    return scenes.Scene("wolf", P, scenes.look_at(eye, centre, up=(0.0, -1.0, 0.0))[None], scenes._intrinsics(1.25 * W, W, H)[None], W, H)
+
+
+@pytest.mark.parametrize("kind,cam,opacity_scale", [("lego", 3, 1.0), ("wolf", 0, 1.0), ("wolf", 0, 0.1)])
+def test_forward_in_segments_agrees_with_the_serial_forward_at_full_size(dev, kind, cam, opacity_scale):
+    """The opt-in forward in segments on whole frames: S1 (lists of hundreds), the wolf frame as it is (pixels saturate early:
+    most heavy tiles have pixels stopping in several segments) and with every opacity at a tenth (lists walked to their ends).
+    Render, alpha and last contributor against the serial forward; then the backward from what the segmented forward left
+    (checkpoints written by the combine pass, items of segments nobody walked past switched off) against the serial backward."""
+    ops = _ops()
+    sc = _scene(kind) if kind != "wolf" else _wolf_frame(dev, opacity_scale)
+    W, H = sc.width, sc.height
+    g, vm, K, radii, splats, keys = _project(sc, dev, cam)
+    b = ops.bin_tiles(radii, splats, W, H, 16, tight=True)
+    bg = torch.tensor([[0.3, 0.6, 0.1]], device=dev)
+    gen = torch.Generator().manual_seed(10)
+    vr = (torch.rand(1, H, W, 3, generator=gen) - 0.5).to(dev)
+    va = (torch.rand(1, H, W, 1, generator=gen) - 0.5).to(dev)
+    r0, a0, l0 = [t.clone() for t in ops.rasterize_fwd(splats, b, W, H, 16, bg, {})]
+    serial = ops.rasterize_bwd(splats, b, W, H, a0, l0, vr, va, 16, bg, False).clone()
+    ws = ops.raster_seg_workspace(b, 1, dev)
+    try:
+        ops.set_raster_fwd_segments(True)
+        for rep in range(2):             # twice: a forward with no backward behind it must leave nothing in the next one's way
+            r1, a1, l1 = [t.clone() for t in ops.rasterize_fwd(splats, b, W, H, 16, bg, {}, seg_ws=ws)]
+        ctl = ws[:12].view(torch.int32).cpu()
+        seg = ops.rasterize_bwd(splats, b, W, H, a1, l1, vr, va, 16, bg, False, render=r1, seg_ws=ws)
+    finally:
+        ops.set_raster_fwd_segments(False)
+    off = b["isect_offsets"].flatten().cpu().long()
+    lens = torch.cat([off[1:], b["n_isect"].cpu().long().reshape(1)]) - off
+    heavy = lens > 256
+    assert int(ctl[2]) == int(heavy.sum()) > 50 and int(ctl[0]) == int(((lens[heavy] + 255) // 256).sum()), (ctl, int(heavy.sum()))
+    assert int(ws[:12].view(torch.int32).abs().sum().item()) == 0
+    assert float((r1 - r0).abs().max()) < 2e-4 and float((a1 - a0).abs().max()) < 2e-4
+    assert int(((r1 - r0).abs().amax(-1) > 3e-6).sum()) <= 8 and int((l1 != l0).sum()) <= 8, \
+        (int(((r1 - r0).abs().amax(-1) > 3e-6).sum()), int((l1 != l0).sum()))
+    assert bool(torch.isfinite(seg).all())
+    for c in range(9):
+        x, y = seg[0, :, c].double(), serial[0, :, c].double()
+        assert float((x - y).norm() / y.norm().clamp(min=1e-30)) < 3e-4, (c, float((x - y).norm() / y.norm()))
+    assert ops._lib.async_errors() == 0
+
+
 def test_s2_training_step_properties_and_fused_adam(dev):
     """One whole training step of the bench configuration (2 M Gaussians, 1080p, capacity mode, fused
     binning, fused backward + Adam) against the unfused sequence on the same inputs; then the properties."""

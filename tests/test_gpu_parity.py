@@ -285,6 +285,53 @@ def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, b
         assert (v0[..., 9] * (1 + 1e-4) + 1e-9 >= v0[..., 0].abs()).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("bg,n_views", [(True, 2), (False, 1)])
+def test_forward_in_segments_matches_oracle_and_the_serial_forward(dev, bg, n_views):
+    """The opt-in forward in segments (mi3dgs_debug_set_raster_fwd_segments(1)): lists of more than 256 entries walked as
+    segments side by side, strung together per pixel, the segments pixels stop in walked once more.  Same scene as above (lists
+    thousands long, pixels that reach their ends, solid splats that stop others half way): render, alpha and every gradient held
+    to the float64 oracle, and to the serial forward of the same library at float rounding."""
+    import mi3dgs
+    from mi3dgs import ops
+    sc = small_scene(n=8000, seed=21, big=True, width=192, height=160, n_views=n_views)
+    g = torch.Generator().manual_seed(5)
+    sc.params["opacities"] = torch.rand(8000, generator=g) * 1.5 - 5.0
+    sc.params["opacities"][:400] = 1.0                                        # solid ones: pixels stop in the middle of lists
+    A = activated(sc.params)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in A.items()}
+    bgs = torch.rand(n_views, 3, generator=g).double() if bg else None
+    r_ref, a_ref, _ = O.rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opacities"], leaves["sh"],
+                                      sc.viewmats.double(), sc.Ks.double(), sc.width, sc.height, sh_degree=3, backgrounds=bgs)
+    wr = torch.randn(r_ref.shape, generator=g).double()
+    wa = torch.randn(a_ref.shape, generator=g).double()
+    ((r_ref * wr).sum() + (a_ref * wa).sum()).backward()
+    out = []
+    try:
+        for fwd_segments in (True, False):
+            ops.set_raster_fwd_segments(fwd_segments)
+            gl = {k: v.detach().float().to(dev).requires_grad_(True) for k, v in A.items()}
+            r, a, meta = mi3dgs.rasterization(gl["means"], gl["quats"], gl["scales"], gl["opacities"], gl["sh"], sc.viewmats.to(dev),
+                                              sc.Ks.to(dev), sc.width, sc.height, sh_degree=3,
+                                              backgrounds=None if bgs is None else bgs.float().to(dev), segments=True)
+            ctl = meta["seg_ws"][:12].view(torch.int32).cpu()
+            ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
+            assert int(meta["seg_ws"][:12].view(torch.int32).abs().sum().item()) == 0
+            out.append((r.detach().cpu(), a.detach().cpu(), meta["last_ids"].cpu(), {k: gl[k].grad.cpu() for k in gl}, ctl))
+    finally:
+        ops.set_raster_fwd_segments(False)
+    (r1, a1, l1, g1, ctl1), (r0, a0, l0, g0, ctl0) = out
+    assert int(ctl1[2]) >= 8 * n_views and int(ctl1[0]) >= 60 * n_views and int(ctl0[2]) == 0, (ctl1, ctl0)   # heavy tiles, segments
+    assert rel_err(r1, r_ref.detach()) < 1e-4 and rel_err(a1, a_ref.detach()) < 1e-4
+    # against the serial forward: float rounding; a pixel within an ulp of the 1e-4 stop may end elsewhere (bounded by 1e-4)
+    assert float((r1 - r0).abs().max()) < 2e-4 and float((a1 - a0).abs().max()) < 2e-4
+    assert int(((r1 - r0).abs().amax(-1) > 3e-6).sum()) <= 4 and int((l1 != l0).sum()) <= 4
+    for k in ("means", "quats", "scales", "opacities", "sh"):
+        e_seg = rel_err(g1[k], leaves[k].grad)
+        assert e_seg < 2e-3, (k, e_seg)
+        assert rel_err(g1[k], g0[k]) < 2e-4, (k, rel_err(g1[k], g0[k]))
+
+
 def test_absgrad_record(dev):
     sc = small_scene(n=200, seed=9, big=True)
     (_, _, _, _), (r, a, meta, gl) = _run_both(sc, dev, 3, True, "classic", absgrad=True)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--modes", nargs="*", type=int, default=None, help="raster mode per lib (experiments builds), default 1")
     ap.add_argument("--seg", nargs="*", type=int, default=None, help="1 = with the segment workspace, per lib (ABI >= 5)")
     ap.add_argument("--wolf-size", nargs=2, type=int, default=[960, 720], help="image size of the wolf scene")
+    ap.add_argument("--opacity-scale", type=float, default=1.0, help="multiply every opacity: < 1 makes the lists be walked to their ends")
     a = ap.parse_args()
     from mi3dgs import _lib, ops, scenes
     dev = torch.device("cuda:0")
@@ -43,6 +44,8 @@ def main():
         sc = scenes.make_scene(a.scene)
     W, H = sc.width, sc.height
     g = {k: v.to(dev) for k, v in sc.params.items()}
+    if a.opacity_scale != 1.0:
+        g["opacities"] = torch.logit((torch.sigmoid(g["opacities"]) * a.opacity_scale).clamp(1e-4, 0.999))
     vm, K = sc.viewmats[a.cam:a.cam + 1].to(dev).contiguous(), sc.Ks[a.cam:a.cam + 1].to(dev).contiguous()
     N = g["means"].shape[0]
     radii, splats = ops.project_fwd(g["means"], g["quats"], g["scales"], g["opacities"], vm, K, W, H, sh0=g["sh0"], shN=g["shN"],
@@ -128,7 +131,9 @@ def main():
             res_items = None
         res.append(dict(lib=path, mode=(a.modes[i] if a.modes else 1), seg_items=res_items, bwd_us_median=sorted(tb[i])[len(tb[i]) // 2], bwd_us_min=min(tb[i]),
                         fwd_us_median=sorted(tf[i])[len(tf[i]) // 2], rel_diff_vs_first=err,
-                        fwd_equal_first=bool(torch.equal(fo[i][0], fo[0][0]) and torch.equal(fo[i][2], fo[0][2]))))
+                        fwd_equal_first=bool(torch.equal(fo[i][0], fo[0][0]) and torch.equal(fo[i][2], fo[0][2])),
+                        fwd_max_abs_diff=float((fo[i][0] - fo[0][0]).abs().max()), alpha_max_abs_diff=float((fo[i][1] - fo[0][1]).abs().max()),
+                        last_ids_differ=int((fo[i][2] != fo[0][2]).sum())))
     probe = None
     for i, h in enumerate(handles):          # a probe build among the libraries: duration of every tile's own block against its list length
         if not hasattr(h, "mi3dgs_debug_read_rb_stamps"):
