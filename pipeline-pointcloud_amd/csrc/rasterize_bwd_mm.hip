@@ -545,7 +545,15 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 // The first `n_workers` blocks loop over the forward's work list (they are resident from the start of the launch and run beside
 // the tiles' own blocks; behind them they were a tail: measured 425 -> 462 us on S2 with 577 items); the blocks behind them
 // take one tile each.  Idle workers cost ~7 ns each.
-constexpr int SEG_WORKERS = 512;      // (1 024 measured the same, profiles/r03_raster_bwd_segments_ab.txt)
+// Dedicated workers, each with a static share of the items.  Few items (wolf 558, S1 970): 512 workers; 1 024 cost wolf 6 us of
+// 119.  Many (MCMC at its cap: ~7 000 items, the tiles' own blocks done after two batches): 512 workers are half the device's
+// slots and the other half stands empty -- rasterize_bwd 700 us at 512, 477 at 1 024, 480 at 2 048, 495 at 4 096, 567 at 8 192;
+// the whole 30 000-step run 48.3 -> 44.3 s (profiles/r03_bwd_workers.txt).  Which case: the workspace's capacity (the launcher).
+// Handing the items out by ticket instead (tiles' blocks joining in when done) was built and measured: same-address atomics from
+// 3 000 blocks drain at ~30 ns each -- wolf 120 -> 208 us with a ticket and a count-out per block, 134 us with compare-and-swap
+// tickets and no count-out (MCMC: 1 455 us of retries).
+constexpr int SEG_WORKERS = 512, SEG_WORKERS_MANY = 1024;
+constexpr size_t SEG_MANY_ITEMS = 4096;      // workspace sized for more than a million intersections
 
 template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
@@ -565,11 +573,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
         // The workers leave the counter clear for the next forward: one thread per worker reads it and counts itself in; the
         // last one to do so resets both words (every reader has read by then).  A clear per forward was a launch per step.
         if (threadIdx.x == 0) {
-            s_items = (int)min(__hip_atomic_load(&seg.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seg.cap);
-            if (__hip_atomic_fetch_add(&seg.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)n_workers - 1u) {
-                __hip_atomic_store(&seg.ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&seg.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&seg.ctl[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_items = (int)min(__hip_atomic_load(&seg.ctl[SEG_CTL_ITEMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), seg.cap);
+            if (__hip_atomic_fetch_add(&seg.ctl[SEG_CTL_OUT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)n_workers - 1u) {
+                __hip_atomic_store(&seg.ctl[SEG_CTL_ITEMS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&seg.ctl[SEG_CTL_OUT], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&seg.ctl[SEG_CTL_HEAVY], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -614,7 +622,10 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
         MI_REQUIRE(seg_ws_layout(n_tiles, seg_ws, seg_ws_bytes, &seg), "rasterize_bwd: segment workspace too small");
         if (!seg_ws_in_use(n_tiles, seg_ws_bytes)) seg = SegWs{};      // as the forward decided
     }
-    const int n_workers = seg.ckpt ? SEG_WORKERS : 0;
+    // (the workspace was sized for max_isect / 256 + n_tiles + 16 items: what is beyond the tiles' share is the host's only
+    //  estimate of how many intersections the caller expects)
+    const bool many_items = seg.ckpt && (size_t)seg.cap > (size_t)n_tiles + 16 + SEG_MANY_ITEMS;
+    const int n_workers = seg.ckpt ? (many_items ? SEG_WORKERS_MANY : SEG_WORKERS) : 0;
     const int grid = raster_grid(n_tiles, tile_width) + n_workers;
 #define LAUNCH_MM(BG, AG, E, SH)                                                                                                 \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \

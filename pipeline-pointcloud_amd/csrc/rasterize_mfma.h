@@ -259,8 +259,12 @@ struct PixelBasis { float u, v, uu, uv, vv; };
 // +4 us, backward +4 us).  The capacity per tile is the host-side proxy for that regime: above 1 024 entries per tile, on a grid
 // of at least 4 096 tiles, both rasterisers ignore the workspace (seg_ws_in_use) and run as if none had been given.
 constexpr int SEG_MIN = 256;              // = BLOCK: the forward can only stop at its batch boundaries
+// control words (the first bytes of the workspace)
+constexpr int SEG_CTL_ITEMS = 0;      // work items the forward booked
+constexpr int SEG_CTL_OUT = 1;        // backward: dedicated workers that have read SEG_CTL_ITEMS
+constexpr int SEG_CTL_HEAVY = 2;      // forward in segments: tiles walked as segments
 struct SegWs {
-    uint32_t* ctl;        // [0] work items handed out, [1] backward workers that have read it, [2] heavy tiles (forward in segments)
+    uint32_t* ctl;        // SEG_CTL_*
     uint32_t* tile_skip;  // [n_tiles] entries at the head of each tile's list that belong to work items (its own block starts behind them)
     uint32_t* heavy;      // [n_tiles] forward in segments: the tiles whose lists are walked as segments
     uint2* tile_items;    // [n_tiles] forward in segments: {first item, segments} of a heavy tile

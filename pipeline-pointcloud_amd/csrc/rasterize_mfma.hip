@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
         if (seg_on && bs > start && ((bs - start) & (int)(seg.seg - 1)) == 0) {
             // somebody composites on beyond this boundary: leave the state for the backward's segment in front of it
             if (threadIdx.x == 0) {
-                const uint32_t slot = atomicAdd(&seg.ctl[0], 1u);
+                const uint32_t slot = atomicAdd(&seg.ctl[SEG_CTL_ITEMS], 1u);
                 s_slot = slot;
                 if (slot < seg.cap) seg.work[slot] = make_uint4((uint32_t)t, (uint32_t)bs - seg.seg, slot, seg.seg);
             }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1024) void fwd_plan_kernel(const int32_t* __restric
         run += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { seg.ctl[0] = (uint32_t)run; seg.ctl[2] = (uint32_t)(run >> 32); }
+    if (threadIdx.x == 0) { seg.ctl[SEG_CTL_ITEMS] = (uint32_t)run; seg.ctl[SEG_CTL_HEAVY] = (uint32_t)(run >> 32); }
 }
 
 template <bool HAS_BG>
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_seg_kernel(int W, int H, 
     const Basis basis = make_basis(wv, lane);
     RF_STAMP(0, wall_clock64()); RF_STAMP(1, 0ull); RF_STAMP(2, 0ull);
     if ((int)blockIdx.x < n_workers) {
-        const int n_items = (int)min(seg.ctl[0], seg.cap);
+        const int n_items = (int)min(seg.ctl[SEG_CTL_ITEMS], seg.cap);
         for (int item = blockIdx.x; item < n_items; item += n_workers) {
             const uint4 wk = seg.work[item];
             const int t = (int)wk.x, lo = (int)wk.y;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_combine_kernel(int W, int H, int tw
                                                             float* __restrict__ render, float* __restrict__ alphas,
                                                             int32_t* __restrict__ last_ids, SegWs seg) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const int n_heavy = (int)seg.ctl[2];
+    const int n_heavy = (int)seg.ctl[SEG_CTL_HEAVY];
     for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const int t = (int)seg.heavy[h];
         const uint2 ti = seg.tile_items[t];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_finish_kernel(int W, int H, int tw,
     __shared__ Staged L;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const Basis basis = make_basis(wv, lane);
-    const int n_items = (int)min(seg.ctl[0], seg.cap);
+    const int n_items = (int)min(seg.ctl[SEG_CTL_ITEMS], seg.cap);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint4 wk = seg.work[item];
         const int enc = seg.local_last[(size_t)wk.z * BLOCK + threadIdx.x];

@@ -168,3 +168,16 @@ def assert_count(name, got, expected, **ctx):
     if int(got) != int(expected):
         raise AssertionError(_evidence(name, dict(kind="count mismatch", got=int(got), expected=int(expected), delta=int(got) - int(expected),
                                                   ctx={k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in ctx.items()})))
+
+
+def seg_ctl(ws):
+    """The segment workspace's control words (csrc/rasterize_mfma.h SEG_CTL_*): items booked by the forward, the backward's
+    dedicated workers counted out, tiles the forward walked as segments."""
+    c = ws[:12].view(torch.int32).cpu().tolist()
+    return dict(items=c[0], out=c[1], heavy=c[2])
+
+
+def assert_seg_clear(ws):
+    """What every backward leaves: nothing booked, nobody counted out."""
+    c = seg_ctl(ws)
+    assert c["items"] == 0 and c["out"] == 0 and c["heavy"] == 0, c

@@ -14,7 +14,8 @@ import math
 import pytest
 import torch
 
-from helpers import activated, assert_clean, assert_count, assert_same, crop_camera, isect_reference, rel_err, wolf_scene
+from helpers import (activated, assert_clean, assert_count, assert_same, assert_seg_clear, crop_camera, isect_reference, rel_err,
+                     seg_ctl, wolf_scene)
 from oracle import gs_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -362,10 +363,10 @@ def test_backward_in_segments_agrees_with_the_serial_walk_at_full_size(dev, kind
     ws = ops.raster_seg_workspace(b, 1, dev)
     r1, a1, l1 = ops.rasterize_fwd(splats, b, W, H, 16, bg, {}, seg_ws=ws)
     assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(l0, l1)          # the checkpoints change nothing in the forward
-    n_items = int(ws[:4].view(torch.int32)[0].item())
+    n_items = seg_ctl(ws)["items"]
     assert n_items > 100, n_items
     seg = ops.rasterize_bwd(splats, b, W, H, a1, l1, vr, va, 16, bg, absgrad, render=r1, seg_ws=ws)
-    assert int(ws[:8].view(torch.int32).abs().sum().item()) == 0
+    assert_seg_clear(ws)
     ncol = 11 if absgrad else 9
     assert bool(torch.isfinite(seg).all())
     for c in range(ncol):
@@ -412,15 +413,15 @@ def test_forward_in_segments_agrees_with_the_serial_forward_at_full_size(dev, ki
         ops.set_raster_fwd_segments(True)
         for rep in range(2):             # twice: a forward with no backward behind it must leave nothing in the next one's way
             r1, a1, l1 = [t.clone() for t in ops.rasterize_fwd(splats, b, W, H, 16, bg, {}, seg_ws=ws)]
-        ctl = ws[:12].view(torch.int32).cpu()
+        ctl = seg_ctl(ws)
         seg = ops.rasterize_bwd(splats, b, W, H, a1, l1, vr, va, 16, bg, False, render=r1, seg_ws=ws)
     finally:
         ops.set_raster_fwd_segments(False)
     off = b["isect_offsets"].flatten().cpu().long()
     lens = torch.cat([off[1:], b["n_isect"].cpu().long().reshape(1)]) - off
     heavy = lens > 256
-    assert int(ctl[2]) == int(heavy.sum()) > 50 and int(ctl[0]) == int(((lens[heavy] + 255) // 256).sum()), (ctl, int(heavy.sum()))
-    assert int(ws[:12].view(torch.int32).abs().sum().item()) == 0
+    assert ctl["heavy"] == int(heavy.sum()) > 50 and ctl["items"] == int(((lens[heavy] + 255) // 256).sum()), (ctl, int(heavy.sum()))
+    assert_seg_clear(ws)
     assert float((r1 - r0).abs().max()) < 2e-4 and float((a1 - a0).abs().max()) < 2e-4
     assert int(((r1 - r0).abs().amax(-1) > 3e-6).sum()) <= 8 and int((l1 != l0).sum()) <= 8, \
         (int(((r1 - r0).abs().amax(-1) > 3e-6).sum()), int((l1 != l0).sum()))

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import activated, rel_err, small_scene
+from helpers import activated, assert_seg_clear, rel_err, seg_ctl, small_scene
 from oracle import gs_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -264,10 +264,10 @@ def test_backward_in_segments_matches_oracle_and_the_serial_walk(dev, absgrad, b
                                           backgrounds=None if bgs is None else bgs.float().to(dev), absgrad=absgrad,
                                           segments=segments)
         if segments:          # work items the forward left; the backward's workers leave the counter clear for the next forward
-            n_items = int(meta["seg_ws"][:4].view(torch.int32)[0].item())
+            n_items = seg_ctl(meta["seg_ws"])["items"]
         ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
         if segments:
-            assert int(meta["seg_ws"][:8].view(torch.int32).abs().sum().item()) == 0
+            assert_seg_clear(meta["seg_ws"])
         grads.append({k: gl[k].grad.cpu() for k in gl})
         metas.append(meta)
     # the case is what it claims to be: every tile's list is thousands long and hundreds of boundaries were walked past
@@ -314,14 +314,14 @@ def test_forward_in_segments_matches_oracle_and_the_serial_forward(dev, bg, n_vi
             r, a, meta = mi3dgs.rasterization(gl["means"], gl["quats"], gl["scales"], gl["opacities"], gl["sh"], sc.viewmats.to(dev),
                                               sc.Ks.to(dev), sc.width, sc.height, sh_degree=3,
                                               backgrounds=None if bgs is None else bgs.float().to(dev), segments=True)
-            ctl = meta["seg_ws"][:12].view(torch.int32).cpu()
+            ctl = seg_ctl(meta["seg_ws"])
             ((r * wr.float().to(dev)).sum() + (a * wa.float().to(dev)).sum()).backward()
-            assert int(meta["seg_ws"][:12].view(torch.int32).abs().sum().item()) == 0
+            assert_seg_clear(meta["seg_ws"])
             out.append((r.detach().cpu(), a.detach().cpu(), meta["last_ids"].cpu(), {k: gl[k].grad.cpu() for k in gl}, ctl))
     finally:
         ops.set_raster_fwd_segments(False)
     (r1, a1, l1, g1, ctl1), (r0, a0, l0, g0, ctl0) = out
-    assert int(ctl1[2]) >= 8 * n_views and int(ctl1[0]) >= 60 * n_views and int(ctl0[2]) == 0, (ctl1, ctl0)   # heavy tiles, segments
+    assert ctl1["heavy"] >= 8 * n_views and ctl1["items"] >= 60 * n_views and ctl0["heavy"] == 0, (ctl1, ctl0)   # heavy tiles, segments
     assert rel_err(r1, r_ref.detach()) < 1e-4 and rel_err(a1, a_ref.detach()) < 1e-4
     # against the serial forward: float rounding; a pixel within an ulp of the 1e-4 stop may end elsewhere (bounded by 1e-4)
     assert float((r1 - r0).abs().max()) < 2e-4 and float((a1 - a0).abs().max()) < 2e-4

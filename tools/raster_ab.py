@@ -145,7 +145,7 @@ def main():
         buf = np.zeros((16384, 3), dtype=np.uint64)
         h.mi3dgs_debug_read_rb_stamps(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes))
         nt = b["tile_width"] * b["tile_height"]
-        nw = 512 if h._seg is not None else 0
+        nw = 512 if h._seg is not None else 0          # (SEG_WORKERS; 1 024 for workspaces sized beyond a million intersections)
         st = buf[nw:nw + nt].astype(np.int64)
         ok = (st[:, 1] > 0) & (st[:, 2] > 0)
         dur, ln = (st[ok, 1] - st[ok, 0]) / 100.0, st[ok, 2].astype(np.float64)
