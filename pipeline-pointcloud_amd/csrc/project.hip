@@ -814,8 +814,12 @@ __global__ __launch_bounds__(256) void project_bwd1_kernel(
     __builtin_amdgcn_wave_barrier();
     if (!FUSE) {
         slice_store(v_shN + 45 * (long long)n0, slice, count, lane);
-    } else if (!MI_BWD_SKIP(flags, 128)) {
+    } else if (!MI_BWD_SKIP(flags, 128) && count > 0) {
         // ---- Adam on the wave's shN slice: gradients from LDS, p / m / v streamed with 16-byte accesses
+        // (count > 0: a wave wholly behind the last Gaussian -- the tail of the last block -- has nothing here, and its clamped
+        //  load index below would be -1 at an offset past the end of the arrays: reads of up to 45 * 4 * 192 bytes beyond them,
+        //  harmless inside a caching allocator's segment and a device fault at a segment's end.  Found late in round 3 by a test
+        //  order that put a 333-Gaussian bank at the end of one.)
         const long long off = 45 * (long long)n0;
         const int n4 = count >> 2;
         const float4* g4 = reinterpret_cast<const float4*>(slice);

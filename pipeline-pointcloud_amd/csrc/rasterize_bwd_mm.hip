@@ -68,7 +68,7 @@ struct StagedBwdMM {
     float2 geo2[STG];         // C, 1 / o
     int id[STG];
     float accw[4][GRP][AW];
-    unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (value, splat of the chunk), columns = the wave's 64 pixels
+    alignas(16) unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (value, splat of the chunk), columns = the wave's 64 pixels
     unsigned long long gmask[4];        // per wave: slots of the current group whose visit was live (its sums are meaningful)
     int wave_max[4];
 };
@@ -287,7 +287,7 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, co
 
 #ifdef MI3DGS_OS_STAMPS
 // Probe build only (tools/raster_probe.py): start / end wall-clock stamps (100 MHz) and list length of every tile's block.
-__device__ unsigned long long g_rb_stamps[16384][3];
+__device__ unsigned long long g_rb_stamps[16384][8];      // start, end, walked entries; prologue done, first records staged, first group walked, pixel values in and reduced
 #define RB_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_rb_stamps[blockIdx.x][i] = (v); } while (0)
 }  // namespace mfma_raster
 extern "C" int mi3dgs_debug_read_rb_stamps(void* dst, size_t bytes) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     __syncthreads();
     const int bmax = max(max(L.wave_max[0], L.wave_max[1]), max(L.wave_max[2], L.wave_max[3]));
     if (bmax < start) return;
-    RB_STAMP(2, (unsigned long long)(bmax - start + 1));
+    RB_STAMP(2, (unsigned long long)(bmax - start + 1)); RB_STAMP(6, wall_clock64());
     const Basis basis = make_basis(wv, lane);
 
     // the B operands of the contraction and this lane's place in its result.
@@ -404,37 +404,34 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     MMLane mm;
     {
         const int j = lane & 15, g = lane >> 4;
-        L.tr[wv][0][lane] = __builtin_bit_cast(unsigned, vr0);
-        L.tr[wv][1][lane] = __builtin_bit_cast(unsigned, vr1);
-        L.tr[wv][2][lane] = __builtin_bit_cast(unsigned, vr2);
+        // Every lane writes the twelve column values of ITS pixel (bf16, in both halves of a word) into twelve transposition
+        // rows; a lane's operand for MFMA m is then four consecutive words of row j: one 128-bit read.  (Until late in round 3
+        // each lane worked the sixteen values out itself -- pixel coordinates, selects by column, conversions, sixteen times over:
+        // ~640 VALU instructions, 7.1 us of a short block's 16.2 at four waves per SIMD; tools/raster_ab.py probe.)
+        {
+            unsigned* const trw = &L.tr[wv][0][lane];
+            const float bas[6] = {px.u, px.v, px.uu, px.uv, px.vv, 1.f};
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const unsigned hb = __builtin_bit_cast(unsigned, bas[c]) >> 16;          // exact
+                trw[c * TR_STRIDE] = hb | (hb << 16);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float val = vrgb[c];                                               // 0 outside the image
+                const unsigned hi = f32_hi(val);
+                const f2v r = {val - __builtin_bit_cast(float, hi), 0.f};
+                const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v)) & 0xFFFFu;
+                trw[(6 + c) * TR_STRIDE] = (hi >> 16) | hi;
+                trw[(9 + c) * TR_STRIDE] = lo | (lo << 16);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // same-wave LDS hand-off
         __builtin_amdgcn_wave_barrier();
-        const int cch = j < 9 ? j - 6 : j - 9;                      // colour channel of columns 6..11 (others: unused)
-        const unsigned* vrow = &L.tr[wv][(cch >= 0 && cch < 3) ? cch : 0][4 * g];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            u4v w;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                int qx, qy;
-                pixel_of_lane(wv, 16 * m + 4 * g + e, qx, qy);
-                const float u = (float)qx - 7.5f, v = (float)qy - 7.5f;
-                const float val = __builtin_bit_cast(float, vrow[16 * m + e]);      // v_rgb[cch] of pixel 16 m + 4 g + e (0 outside the image)
-                unsigned hb = 0u;                  // bf16 bits
-                if (j < 6) {
-                    const float bv = j == 0 ? u : j == 1 ? v : j == 2 ? u * u : j == 3 ? u * v : j == 4 ? v * v : 1.f;
-                    hb = __builtin_bit_cast(unsigned, bv) >> 16;          // exact
-                } else if (j < 12) {
-                    const unsigned hi = f32_hi(val);
-                    if (j < 9) hb = hi >> 16;
-                    else {
-                        const f2v r = {val - __builtin_bit_cast(float, hi), 0.f};
-                        hb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v)) & 0xFFFFu;
-                    }
-                }
-                w[e] = hb | (hb << 16);
-            }
-            mm.bop[m] = w;
+            const u4v w = *reinterpret_cast<const u4v*>(&L.tr[wv][j < 12 ? j : 0][16 * m + 4 * g]);      // pixels 16 m + 4 g + 0..3
+            mm.bop[m] = j < 12 ? w : u4v{0u, 0u, 0u, 0u};
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the rows are rewritten by the first chunk
         __builtin_amdgcn_wave_barrier();
@@ -455,6 +452,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     const unsigned long long has = wave_ballot(bin_final >= 0);
     MMPend P;
     P.on = false;
+    RB_STAMP(3, wall_clock64()); RB_STAMP(4, 0ull); RB_STAMP(5, 0ull);
     for (int be = bmax; be >= start; be -= STG) {
         __syncthreads();
         if (tid < STG) {
@@ -469,6 +467,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
             }
         }
         __syncthreads();
+        if (be == bmax) RB_STAMP(4, wall_clock64());
         const int bsz = min(STG, be - start + 1);
         const int k0 = max(0, be - wmax);            // wave-uniform: nothing in this wave is live before slot k0
         for (int g0 = 0; g0 < bsz; g0 += GRP) {      // block-uniform: groups of 64 slots
@@ -487,6 +486,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
             if (EXP & 5) continue;          // 1: timing experiment, no group barriers, no flush; 4: the waves have flushed themselves
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
+            if (be == bmax && g0 == 0) RB_STAMP(5, wall_clock64());
             // flush: lane -> (slot = lane >> 4, column = lane & 15), 16 slots per round over the block.  A wave's 4 slots lie in
             // one chunk, so "which quadrants have sums for it" is wave-uniform.  The gradients of (x, y, conic A, B, C, opacity)
             // follow from the moments about the tile centre:

@@ -137,16 +137,25 @@ __device__ __forceinline__ unsigned basis_slot_bits(int slot, float u, float v) 
 
 __device__ __forceinline__ Basis make_basis(int wave, int lane) {
     Basis b;
-    const int h = lane >> 5;
+    const bool h1 = (lane >> 5) != 0;
     int lx, ly;
 #pragma unroll
     for (int blk = 0; blk < 2; blk++) {
         pixel_of_lane(wave, 32 * blk + (lane & 31), lx, ly);
         const float u = (float)lx - 7.5f, v = (float)ly - 7.5f;
+        // the six basis values once (bf16 bits, exact), then the words of slots 8 h + 2 e, 8 h + 2 e + 1 (slot s multiplies basis
+        // s / 3) for both halves of the wave and ONE select per word -- basis_slot_bits with a run-time slot was a six-way select
+        // chain per half word, twenty of them per call, at the head of every forward and backward block
+        unsigned k[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) k[i] = basis_slot_bits(3 * i, u, v);
+        // h = 0: slots (0,1) (2,3) (4,5) (6,7) -> bases (0,0) (0,1) (1,1) (2,2); h = 1: slots (8,9) .. (14,15) -> (2,3) (3,3) (4,4) (4,5)
+        const unsigned w0[4] = {k[0] | (k[0] << 16), k[0] | (k[1] << 16), k[1] | (k[1] << 16), k[2] | (k[2] << 16)};
+        const unsigned w1[4] = {k[2] | (k[3] << 16), k[3] | (k[3] << 16), k[4] | (k[4] << 16), k[4] | (k[5] << 16)};
         qu4 w;
 #pragma unroll
-        for (int e = 0; e < 4; e++) w[e] = basis_slot_bits(8 * h + 2 * e, u, v) | (basis_slot_bits(8 * h + 2 * e + 1, u, v) << 16);
-        const unsigned w2 = h == 0 ? (basis_slot_bits(16, u, v) | (basis_slot_bits(17, u, v) << 16)) : 0u;
+        for (int e = 0; e < 4; e++) w[e] = h1 ? w1[e] : w0[e];
+        const unsigned w2 = h1 ? 0u : (k[5] | (k[5] << 16));           // slots 16, 17
         if (blk == 0) { b.x1 = w; b.x2 = w2; } else { b.y1 = w; b.y2 = w2; }
     }
     return b;

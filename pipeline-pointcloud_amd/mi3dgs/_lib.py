@@ -171,9 +171,18 @@ def async_errors(reset: bool = True) -> int:
 STAGE_HOOK = None
 
 
+_SYNC_EACH_CALL = os.environ.get("MI3DGS_SYNC_EACH_CALL") == "1"      # debugging aid: a device fault surfaces in the call that caused it
+
+
 def call(name: str, *args) -> None:
     fn = getattr(lib(), name)
-    if STAGE_HOOK is None:
+    if _SYNC_EACH_CALL:
+        import sys
+        import torch
+        check(fn(*args))
+        print(f"[mi3dgs sync] {name}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+    elif STAGE_HOOK is None:
         check(fn(*args))
     else:
         STAGE_HOOK(name, lambda: check(fn(*args)))

@@ -829,6 +829,41 @@ def test_fused_adam_backward_equals_separate_kernels(dev, n, scale_reg):
     assert rel_err(out[True][0]["means"], g.params["means"]) > 1e-6
 
 
+def test_fused_backward_reads_nothing_behind_the_last_gaussian(dev):
+    """The fused backward + Adam launches whole 256-thread blocks: with 332 Gaussians the second block's last two waves own no
+    Gaussian at all.  Their (clamped) loads of the shN parameter and moment arrays once went to index -1 of an offset past the
+    arrays' end -- harmless inside an allocator segment, a device fault where a bank ends with its segment (a test order that
+    did that took the process down).  Here every array ends exactly at the end of an allocation of its own."""
+    from mi3dgs import ops, trainer
+    n = 332                                           # 332 * 45 floats is a multiple of 16 bytes: the views below stay aligned
+    sc = small_scene(n=n, seed=52, big=True, width=80, height=56, n_views=1)
+    g = sc.to(dev)
+
+    def at_end(t):                                    # the tensor's values in the LAST bytes of a 12 MiB allocation (a segment of its own)
+        buf = torch.zeros((12 << 20) // 4, dtype=torch.float32, device=dev)
+        v = buf[buf.numel() - t.numel():].view(t.shape)
+        v.copy_(t)
+        return v, buf
+
+    keep = []
+    params, m1, m2 = [], [], []
+    for k in trainer.GROUPS:
+        for lst, src in ((params, g.params[k].float()), (m1, torch.zeros_like(g.params[k]).float()), (m2, torch.zeros_like(g.params[k]).float())):
+            v, buf = at_end(src.contiguous())
+            lst.append(v); keep.append(buf)
+    vm, K = g.viewmats[:1].contiguous(), g.Ks[:1].contiguous()
+    radii, splats = ops.project_fwd(params[0], params[1], params[2], params[3], vm, K, 80, 56, sh0=params[4], shN=params[5], sh_degree=3,
+                                    flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC)
+    v_splats = torch.randn(1, n, ops.GRAD_STRIDE, device=dev) * 1e-3
+    before = params[5].clone()
+    for sh_degree in (0, 3):
+        ops.project_bwd_adam(params, m1, m2, (1e-4, 1e-3, 5e-3, 5e-2, 2.5e-3, 1.25e-4), 1, vm, K, 80, 56, radii, splats, v_splats,
+                             n=n, sh_degree=sh_degree, flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(params[5]).all()) and not torch.equal(params[5], before)
+    assert ops._lib.async_errors() == 0
+
+
 # --------------------------------------------------------------------------- MCMC strategy
 def test_mcmc_relocation_matches_oracle(dev):
     from mi3dgs import strategy_mcmc

@@ -142,7 +142,7 @@ def main():
         outs[i].zero_()
         h.mi3dgs_rasterize_bwd(*bwd_args(h, outs[i]))
         torch.cuda.synchronize()
-        buf = np.zeros((16384, 3), dtype=np.uint64)
+        buf = np.zeros((16384, 8), dtype=np.uint64)
         h.mi3dgs_debug_read_rb_stamps(C.c_void_p(buf.ctypes.data), C.c_size_t(buf.nbytes))
         nt = b["tile_width"] * b["tile_height"]
         nw = 512 if h._seg is not None else 0          # (SEG_WORKERS; 1 024 for workspaces sized beyond a million intersections)
@@ -160,6 +160,13 @@ def main():
         probe_extra = dict(sum_block_us=round(float(dur.sum()), 0), ideal_span_us_at_1024_slots=round(float(dur.sum()) / 1024, 1),
                            active_blocks_per_sixteenth=[int(round(x)) for x in act],
                            mean_walk_of_first_and_last_quarter_started=[int(ln[order[: len(order) // 4]].mean()), int(ln[order[-len(order) // 4:]].mean())])
+        # where a SHORT block's time goes (at most 64 walked entries: one group, one flush)
+        sh = ok & (st[:, 2] <= 64) & (st[:, 3] > 0) & (st[:, 4] > 0) & (st[:, 5] > 0)
+        if sh.any():
+            q = st[sh]
+            med = lambda x: round(float(np.median(x)) / 100.0, 2)
+            probe_extra["short_block_phases_us_median"] = dict(blocks=int(sh.sum()), pixel_values_and_reductions=med(q[:, 6] - q[:, 0]), operands=med(q[:, 3] - q[:, 6]), list_and_records=med(q[:, 4] - q[:, 3]),
+                                                                walk=med(q[:, 5] - q[:, 4]), flush=med(q[:, 1] - q[:, 5]), total=med(q[:, 1] - q[:, 0]))
         probe = dict(lib=a.libs[i], blocks_with_work=int(ok.sum()), **probe_extra, fit_us=dict(fixed=round(float(coef[0]), 2), per_1000_entries=round(float(coef[1] * 1000), 2)),
                      duration_us=dict(median=round(float(np.median(dur)), 1), p90=round(float(np.percentile(dur, 90)), 1), max=round(float(dur.max()), 1)),
                      walked_entries=dict(median=int(np.median(ln)), p90=int(np.percentile(ln, 90)), max=int(ln.max())), span_us=round(float(span), 1),
