@@ -31,6 +31,14 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s 
 F32_PEAK_TFLOPS = 157.3      # f32 MFMA == f32 vector peak
 
 
+# the reference call site each preset stands for
+PRESET_JOBS = {
+    "splatfacto": "ns-train splatfacto --pipeline.model.use_scale_regularization=True (source/container/src/main.py:1270-1306): absgrad, "
+                  "scale regulariser every 10 steps, random background, screen-size statistics, prune_opa 0.1 / grow_grad2d 8e-4",
+    "simple_trainer": "gsplat examples/simple_trainer.py default (source/container/src/main.py:1318-1347): DefaultStrategy defaults, no absgrad, "
+                      "no regulariser, no background",
+}
+
 _T0 = time.time()
 
 
@@ -55,21 +63,34 @@ def parse():
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a ONE-GPU box: gloo backend, every rank on cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group (RCCL; gloo with --rehearse) and run every barrier / all-reduce even at WORLD_SIZE 1: "
+                         "the multi-GPU code path on a one-GPU box (launch with torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--param-checksum", action="store_true",
+                    help="add `param_checksum` (wrap-around sum of the parameters' bit patterns after the timed steps) to the line")
+    ap.add_argument("--verify-shard-step", action="store_true",
+                    help="scene-shard: after the timed steps take one more step and recompute it from a snapshot with the dense "
+                         "single-GPU Adam on the same reduced gradients; `shard_step_bit_exact` in the line")
     ap.add_argument("--sync-isect", action="store_true", help="read the intersection count back every step")
     ap.add_argument("--no-spatial-sort", action="store_true", help="A/B: keep the generator's (random) order of the Gaussians")
     ap.add_argument("--overlap-adam", default="after_binning", choices=["off", "after_project", "after_binning", "after_raster_fwd"],
                     help="Adam of the fully culled 64-Gaussian groups on a second stream (TrainConfig.overlap_culled_adam, as the CLI "
                          "runs it); off / other launch points for the A/B")
+    ap.add_argument("--preset", default="splatfacto", choices=["splatfacto", "simple_trainer"],
+                    help="which of the reference's two training jobs a step is: `ns-train splatfacto` (main.py:1270-1306, the pipeline's "
+                         "default: absgrad, scale regulariser every 10 steps, random background, screen-size statistics) -- `value` -- or "
+                         "gsplat's `simple_trainer default` (main.py:1318-1347).  The other preset is timed beside it (`presets`).")
+    ap.add_argument("--one-preset", action="store_true", help="do not time the other preset beside the chosen one")
     ap.add_argument("--two-phase-binning", action="store_true",
                     help="A/B: mi3dgs_bin_count + mi3dgs_bin_emit instead of the fused mi3dgs_bin_tiles")
     return ap.parse_args()
 
 
-def setup_dist(n_gpus, rehearse=False):
+def setup_dist(n_gpus, rehearse=False, force=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -115,36 +136,102 @@ def build_workload(args, rank, dev):
     imgs = torch.cat(imgs)
     del tr0
     torch.cuda.empty_cache()
-    n = g.params["means"].shape[0]
-    cfg = trainer.TrainConfig(
+    data = dict(params=g.params, vm=vm, ks=ks, imgs=imgs)
+    tr = make_trainer(args, args.preset, sc, data, rank, dev)
+    return sc, tr, V, data
+
+
+def preset_config(args, preset, n):
+    """TrainConfig of one of the reference's two training jobs, at the named workload's fixed size."""
+    import dataclasses
+    from mi3dgs import cli, trainer
+    common = dict(
         max_steps=30_000, capacity=n + n // 8,
         # fixed-N workload: the densify statistics are accumulated every step (their cost is inside the
-        # step); the every-100-steps refine pass is NOT inside the timed steps -- main() times one
-        # refine() after them and reports `refine_ms` and the amortised rate next to `value`
+        # step); the every-100-steps refine pass is timed right behind the steps and amortised into `value`
         refine_start_iter=10 ** 9,
-        max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning,
+        max_isect=None if args.sync_isect else 0, fused_binning=not args.two_phase_binning, auto_isect_capacity=False,
         # the trainer's load-time Morton ordering of the Gaussians, as the CLI runs it (TrainConfig.spatial_sort_init)
         spatial_sort_init=not args.no_spatial_sort,
         overlap_culled_adam=None if args.overlap_adam == "off" else args.overlap_adam)
+    if preset == "splatfacto":
+        # `ns-train splatfacto --pipeline.model.use_scale_regularization=True` exactly as mi3dgs/cli.py configures it for the
+        # reference's argv (main.py:1270-1306): absgrad, scale regulariser every 10 steps, random background, the screen-size
+        # rules' statistic (step 3001 < stop_screen_size_at 4000) -- at the workload's full resolution (the coarse-to-fine
+        # schedule has ended by step 6000 of 30 000)
+        base = cli.splatfacto_config("splatfacto", 30_000, True, 8, n + n // 8)
+        return dataclasses.replace(base, num_downscales=0, **common)
+    return trainer.TrainConfig(**common)            # gsplat simple_trainer `default`
+
+
+def make_trainer(args, preset, sc, data, rank, dev):
+    from mi3dgs import trainer
+    n = data["params"]["means"].shape[0]
+    cfg = preset_config(args, preset, n)
+    vm, ks, imgs = data["vm"], data["ks"], data["imgs"]
     if args.mode == "scene-shard":
         import dataclasses
         from mi3dgs import parallel
-        ctx = parallel.DistContext(rank, int(os.environ.get("WORLD_SIZE", "1")), dev.index or 0)
-        tr = parallel.DataParallelTrainer(g.params, vm, ks, imgs, sc.width, sc.height,
-                                          dataclasses.replace(cfg, capacity=n, fuse_adam=ctx.world == 1), ctx=ctx)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        ctx = parallel.DistContext(rank, world, dev.index or 0)
+        if args.force_dist and world == 1:
+            # the one-GPU rehearsal of the multi-GPU path: a one-rank context that still takes every collective branch
+            # (reduce-scatter -> Adam on the slice -> all-gather through the process group), not the fused single-GPU step
+            class _OneRankActive(parallel.DistContext):
+                @property
+                def active(self):
+                    return True
+            ctx = _OneRankActive(rank, 1, dev.index or 0)
+        tr = parallel.DataParallelTrainer(data["params"], vm, ks, imgs, sc.width, sc.height,
+                                          dataclasses.replace(cfg, capacity=n, fuse_adam=not ctx.active), ctx=ctx)
     else:
-        tr = trainer.Trainer(g.params, vm, ks, imgs, sc.width, sc.height, cfg)
-    tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every
+        tr = trainer.Trainer(data["params"], vm, ks, imgs, sc.width, sc.height, cfg)
+    tr.step_count = 3001          # SH degree 3 active (ramp finished); not a multiple of reset_every; every statistic still written
     if not args.sync_isect:
         # size the intersection buffers once (one sync here, none in the loop): 1.5x the worst view
         worst = 0
         tr.cfg.max_isect = None
-        for i in range(V):
+        for i in range(vm.shape[0]):
             tr.render(vm[i], ks[i])
             worst = max(worst, int(tr.last_binning["n_isect"].item()) if hasattr(tr, "last_binning") else 0)
         tr.cfg.max_isect = int(worst * 1.5) + 1024
-        log(f"intersection capacity {tr.cfg.max_isect} (worst view {worst})")
-    return sc, tr, V
+        log(f"[{preset}] intersection capacity {tr.cfg.max_isect} (worst view {worst})")
+    return tr
+
+
+def verify_shard_step(tr, view):
+    """One step of the sharded optimiser (reduce-scatter -> Adam on this rank's rows with 1 / world -> all-gather) against the
+    dense single-GPU update computed from a snapshot and the SAME summed gradients: bit for bit, every rank's verdict ANDed.
+    (Two separate runs can not be compared bit for bit: rasterize_bwd's float atomics meet in a different order every launch.)"""
+    import torch.distributed as dist
+    from mi3dgs import ops
+    from mi3dgs.trainer import GROUPS, WIDTHS
+    m, c = tr.model, tr.cfg
+    n = m.n
+    tr._sync_optimizer_state()                   # every rank's moments current, as at a refine
+    snap = {k: m.flat[k][m.cur].clone() for k in ("p", "m", "v")}
+    lrs, step1 = tr.lrs(), tr.step_count + 1
+    tr.step(view)
+    tr._sync_optimizer_state()
+    g = m.flat["g"].clone()                      # after the reduce-scatter: this rank's rows hold the sum over the ranks
+    world = tr.ctx.world
+    cap = m.capacity
+    offs = [sum(WIDTHS[:i]) * cap for i in range(len(WIDTHS))]
+    if world > 1:                                # the other ranks' rows of the summed gradient
+        for _, off, cnt in tr._group_spans():
+            L = cnt // world
+            parts = [torch.empty(L, dtype=g.dtype, device=g.device) for _ in range(world)]
+            dist.all_gather(parts, g[off + tr.ctx.rank * L: off + (tr.ctx.rank + 1) * L].contiguous())
+            g[off: off + cnt] = torch.cat(parts)
+    ops.adam_step([snap["p"][o: o + w * n] for o, w in zip(offs, WIDTHS)], [g[o: o + w * n] for o, w in zip(offs, WIDTHS)],
+                  [snap["m"][o: o + w * n] for o, w in zip(offs, WIDTHS)], [snap["v"][o: o + w * n] for o, w in zip(offs, WIDTHS)],
+                  lrs, step1, beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps, grad_scale=1.0 / world)
+    ok = all(torch.equal(snap[k][o: o + w * n], m.flat[k][m.cur][o: o + w * n]) for k in ("p", "m", "v") for o, w in zip(offs, WIDTHS))
+    if dist.is_initialized():
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=g.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t.item()))
+    return bool(ok)
 
 
 class StageTimer:
@@ -344,46 +431,86 @@ def main():
     if args.cpu_leg:
         return cpu_leg_main(args.cpu_leg)
     box = box_info()            # before anything touches the GPU
-    rank, world, local = setup_dist(args.gpus, args.rehearse)
+    rank, world, local = setup_dist(args.gpus, args.rehearse, args.force_dist)
+    dist_on = world > 1 or args.force_dist          # collectives run (also at world 1 with --force-dist)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     from mi3dgs import _lib, ops, trainer  # noqa: F401
 
-    sc, tr, V = build_workload(args, rank, dev)
+    sc, tr, V, data = build_workload(args, rank, dev)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier() if args.rehearse else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist_on:
+            import torch.distributed as dist
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     shard = args.mode == "scene-shard"
     view_of = (lambda i: (i * world + rank) % V) if shard else (lambda i: i % V)      # one view per rank per step
-    log("warmup")
-    for i in range(args.warmup):
-        tr.step(view_of(i))
-    sync_all()
-    log("timed region")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        tr.step(view_of(args.warmup + i))
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    its = world * args.steps / dt
-    log(f"{its:.2f} it/s")
-    # a chained kernel that gave up waiting, or a tile list cut at the capacity, would have made the
-    # timed steps wrong without failing them: the number is only published if the sticky word is clean
-    async_bits = _lib.async_errors()
-    if async_bits:
-        raise SystemExit(f"bench: device error word {async_bits:#x} after the timed region (1/2: a chained kernel "
-                         "gave up waiting, 4: tile intersections exceeded isect_capacity); no result published")
+
+    def time_steps(tr_, what):
+        log(f"[{what}] warmup")
+        for i in range(args.warmup):
+            tr_.step(view_of(i))
+        sync_all()
+        log(f"[{what}] timed region")
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            tr_.step(view_of(args.warmup + i))
+        sync_all()
+        dt_ = max_over_ranks(time.perf_counter() - t0)
+        # a chained kernel that gave up waiting, or a tile list cut at the capacity, would have made the
+        # timed steps wrong without failing them: the number is only published if the sticky word is clean
+        bits = _lib.async_errors()
+        if bits:
+            raise SystemExit(f"bench: device error word {bits:#x} after the timed region (1/2: a chained kernel "
+                             "gave up waiting, 4: tile intersections exceeded isect_capacity); no result published")
+        log(f"[{what}] {world * args.steps / dt_:.2f} it/s without the refine pass")
+        return dt_
+
+    def time_refine(tr_, what):
+        """One densify / prune pass at this size (every refine_every = 100 steps in training): decide + scan + scatter of all
+        parameter and moment rows into the spare bank + the host sync on the new count.  Every rank runs it (collective in
+        scene-shard mode); the slowest rank's time counts."""
+        runs = []
+        for rep in range(2):                 # the first call also pays the one-time set-up of a few tensor ops
+            for i in range(3):               # fresh statistics for the pass
+                tr_.step(view_of(i))
+            sync_all()
+            t2 = time.perf_counter()
+            rinfo = tr_.refine(do_grow=True)
+            torch.cuda.synchronize()
+            runs.append((max_over_ranks(1e3 * (time.perf_counter() - t2)), rinfo))
+        refine_ms, rinfo = runs[-1]
+        log(f"[{what}] refine: {refine_ms:.2f} ms ({rinfo['n_before']} -> {rinfo['n_after']} Gaussians; first call {runs[0][0]:.1f} ms)")
+        return dict(refine_ms=refine_ms, first_call_ms=runs[0][0], refine_every=100,
+                    **{k: rinfo[k] for k in ("n_before", "n_after", "n_dup", "n_split", "n_prune")})
+
+    def amortised(dt_, refine_):
+        """it/s of K steps plus their share (K / 100) of a refine pass -- what a training run of this preset sustains."""
+        return world * args.steps / (dt_ + args.steps / 100.0 * refine_["refine_ms"] * 1e-3)
+
+    dt = time_steps(tr, args.preset)
+    async_bits = 0
+    shard_exact = None
+    if args.verify_shard_step and shard:
+        shard_exact = verify_shard_step(tr, view_of(args.warmup + args.steps))
+        log(f"sharded step equals the dense Adam on the same gradients bit for bit: {shard_exact}")
+    checksum = None
+    if args.param_checksum:
+        checksum = 0
+        for g_ in trainer.GROUPS:
+            checksum = (checksum + int(tr.model.p(g_).contiguous().view(torch.int32).to(torch.int64).sum().item())) & 0xFFFFFFFFFFFFFFFF
 
     # ---- render-only FPS (same scene, SH degree 3), untimed-region extra
     torch.cuda.synchronize()
@@ -397,7 +524,6 @@ def main():
     if async_bits:
         raise SystemExit(f"bench: device error word {async_bits:#x} after the render loop; no result published")
 
-    result = None
     if rank == 0:
         n = tr.model.n
         Px = sc.width * sc.height
@@ -446,6 +572,8 @@ def main():
                 # radii (8) and, for the visible ones, the splat and gradient records (128)
                 # (with the culled groups split off: only the Gaussians of groups with a visible member, every radius still read)
                 "project_bwd_adam": n_vgrp * (708 + 708) + n * 8 + n_vis * 128,
+                # (the every-tenth step with splatfacto's scale regulariser: one launch over every Gaussian)
+                "project_bwd_adam/scale_reg": n * (708 + 708) + n * 8 + n_vis * 128,
                 # the culled groups' Adam on the second stream: p, m, v read and written, every radius read
                 "adam_culled_groups": (n - n_vgrp) * (708 + 708) + n * 8,
             }
@@ -535,25 +663,27 @@ def main():
         if not args.no_cpu_baseline and world == 1:        # the CPU leg runs at N = 1 only
             cpu = cpu_baseline(sc, tr, 0)
             log(f"cpu baseline: {cpu.get('value')}")
-        # ---- one densify / prune pass at this size (every refine_every = 100 steps in training): decide +
-        # scan + scatter of all parameter and moment rows into the spare bank + the host sync on the new count
-        refine_runs = []
-        for rep in range(0 if (shard and world > 1) else 2):      # the first call also pays the one-time set-up of a few tensor ops
-            for i in range(3):               # fresh statistics for the pass
-                tr.step(i % V)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            rinfo = tr.refine(do_grow=True)
-            torch.cuda.synchronize()
-            refine_runs.append((1e3 * (time.perf_counter() - t2), rinfo))
-        refine = None
-        if refine_runs:
-            refine_ms, rinfo = refine_runs[-1]
-            step_ms = 1e3 * dt / args.steps
-            refine = dict(refine_ms=refine_ms, first_call_ms=refine_runs[0][0], refine_every=100,
-                          **{k: rinfo[k] for k in ("n_before", "n_after", "n_dup", "n_split", "n_prune")},
-                          amortised_it_per_s=world * 1e3 / (step_ms + refine_ms / 100.0))
-            log(f"refine: {refine_ms:.2f} ms ({rinfo['n_before']} -> {rinfo['n_after']} Gaussians; first call {refine_runs[0][0]:.1f} ms)")
+        xgmi = tr.xgmi_bytes_per_step() if shard else 0
+        isect_cap = tr.cfg.max_isect
+    # ---- every rank: the refine pass of this preset, then the reference's OTHER training job on the same data
+    refine = time_refine(tr, args.preset)
+    its = amortised(dt, refine)
+    presets = {args.preset: dict(it_per_s=its, it_per_s_without_refine=world * args.steps / dt, ms_per_step_without_refine=1e3 * dt / args.steps,
+                                 refine=refine, reference_job=PRESET_JOBS[args.preset])}
+    if not args.one_preset:
+        other = "simple_trainer" if args.preset == "splatfacto" else "splatfacto"
+        del tr
+        torch.cuda.empty_cache()
+        tr2 = make_trainer(args, other, sc, data, rank, dev)
+        dt2 = time_steps(tr2, other)
+        refine2 = time_refine(tr2, other)
+        async_bits |= _lib.async_errors()
+        presets[other] = dict(it_per_s=amortised(dt2, refine2), it_per_s_without_refine=world * args.steps / dt2,
+                              ms_per_step_without_refine=1e3 * dt2 / args.steps, refine=refine2, reference_job=PRESET_JOBS[other])
+        del tr2
+    if async_bits:
+        raise SystemExit(f"bench: device error word {async_bits:#x} after the refine passes; no result published")
+    if rank == 0:
         par = f"scene-per-gpu x{world}"
         what = "one independent scene per GPU"
         if shard:
@@ -562,7 +692,10 @@ def main():
         result = {
             "metric": "3DGS training iterations/s @1080p (render FPS reported alongside)",
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "ms_per_step": 1e3 * world / its, "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "value_note": f"{args.steps} timed steps of the `{args.preset}` preset plus their share ({args.steps}/100) of the every-100-steps "
+                          "densify / prune pass, which is timed right behind them (`refine`): the rate a training run sustains.  "
+                          "`presets` has both of the reference's training jobs on the same data, with and without that share.",
             "vs_baseline": None, "dtype": "f32",
             "dtype_note": "f32 arithmetic and accumulation throughout, except the transport of rasterize_bwd's per-splat pixel "
                           "sums to their f32 accumulators: two bf16 terms per addend (16-bit significand, <= 2^-16 relative, "
@@ -570,15 +703,18 @@ def main():
                           "bf16 coefficients (24 bits, exact products)",
             "data": "synthetic", "box": box,
             "config": {"workload": f"{sc.name}: {n} Gaussians, SH degree 3, {sc.width}x{sc.height}, {V} resident views, {what}",
-                       "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": tr.cfg.max_isect,
-                       "parallelism": par, "mode": args.mode, "gaussians_in_morton_order": bool(tr.cfg.spatial_sort_init),
+                       "preset": args.preset, "reference_job": PRESET_JOBS[args.preset],
+                       "gaussians": n, "visible": n_vis, "intersections": n_isect, "pixels": Px, "isect_capacity": isect_cap,
+                       "parallelism": par, "mode": args.mode, "gaussians_in_morton_order": not args.no_spatial_sort,
                        "culled_groups_adam_on_second_stream": split_adam, "gaussians_in_groups_with_a_visible_member": n_vgrp,
-                       "xgmi_bytes_per_rank_per_step": tr.xgmi_bytes_per_step() if shard else 0},
+                       "xgmi_bytes_per_rank_per_step": xgmi},
+            "presets": presets, "process_group": (("gloo" if args.rehearse else "nccl") if dist_on else None),
+            "param_checksum": checksum, "shard_step_bit_exact": shard_exact,
             "render_fps": fps, "roofline": roof, "render_roofline": render_roof, "refine": refine,
             "async_errors": async_bits, "cpu_baseline": cpu, "stages": stages,
         }
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier() if args.rehearse else dist.barrier(device_ids=[local])
         dist.destroy_process_group()

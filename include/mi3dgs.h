@@ -78,7 +78,7 @@ int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg
  * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
  * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);
-int mi3dgs_abi_version(void);      /* 5 */
+int mi3dgs_abi_version(void);      /* 6 */
 int mi3dgs_splat_stride(void);
 int mi3dgs_grad_stride(void);
 
@@ -309,11 +309,16 @@ int mi3dgs_debug_hbm_stream(float* buf, long long floats_per_array, int n_read, 
  * Replaces gsplat DefaultStrategy._grow_gs/_prune_gs and strategy.ops duplicate / split /
  * remove / reset_opa.  decide -> mi3dgs_scan_exclusive_u32(out_count) -> scatter.
  * Group order everywhere: means[3], quats[4], scales[3], opacities[1], sh0[3], shN[45]. */
+/* stat_radii (nullable): the running maximum of radius / max(W, H) that mi3dgs_project_bwd* accumulates.  Given it, the
+ * screen-size rules of gsplat's DefaultStrategy apply (grow_scale2d / prune_scale2d; nerfstudio splatfacto's split_screen_size
+ * 0.05 / cull_screen_size 0.15 until stop_screen_size_at 4000 -- `ns-train splatfacto`, reference main.py:1270-1306): split
+ * also where it exceeds grow_scale2d, prune (when check_too_big) also where it exceeds prune_scale2d.  The caller passes null
+ * from the stop iteration on.  flags: bit 0 duplicate, bit 1 split (both: the copy and the two samples, 3 outputs), bit 2 prune. */
 int mi3dgs_densify_decide(int N, const float* scales_log, const float* opacities_logit,
-                          const float* stat_grad2d, const float* stat_count, float grow_grad2d,
-                          float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs,
-                          int do_grow, int check_too_big, uint8_t* flags, uint32_t* out_count,
-                          void* stream);
+                          const float* stat_grad2d, const float* stat_count, const float* stat_radii,
+                          float grow_grad2d, float grow_scale3d_abs, float grow_scale2d, float prune_opa,
+                          float prune_scale3d_abs, float prune_scale2d, int do_grow, int check_too_big,
+                          uint8_t* flags, uint32_t* out_count, void* stream);
 /* n_out = the scan's total (the caller has read it back to size / swap its buffers anyway);
  * map_workspace[capacity] u32: for every output row, where it comes from (a row-gather per array follows). */
 int mi3dgs_densify_scatter(int N, long long n_out, const float* const* params_in,

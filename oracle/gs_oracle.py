@@ -418,16 +418,28 @@ def strategy_update_state(state: Dict, means2d_grad: torch.Tensor, radii: torch.
 
 def strategy_masks(state: Dict, scales_exp: torch.Tensor, opacities_sig: torch.Tensor, step: int,
                    scene_scale: float = 1.0, prune_opa: float = 0.005, grow_grad2d: float = 0.0002,
-                   grow_scale3d: float = 0.01, prune_scale3d: float = 0.1, reset_every: int = 3000):
-    """Decision masks of DefaultStrategy._grow_gs / _prune_gs (before any RNG is drawn)."""
+                   grow_scale3d: float = 0.01, prune_scale3d: float = 0.1, reset_every: int = 3000,
+                   grow_scale2d: float = 0.05, prune_scale2d: float = 0.15, refine_scale2d_stop_iter: int = 0):
+    """Decision masks of DefaultStrategy._grow_gs / _prune_gs (before any RNG is drawn).  is_prune is the mask over the
+    ORIGINAL Gaussians, before growth; upstream evaluates it on the grown set, where a split's samples are 1.6 x smaller and
+    every child carries its parent's radius statistic (the caller applies the 1.6).
+    Screen-size rules (refine_scale2d_stop_iter > 0; nerfstudio splatfacto: 0.05 / 0.15 / 4000, reference main.py:1270-1306):
+    state["radii"] = running max of radius / max(W, H); while step < the stop iteration, split also where it exceeds
+    grow_scale2d (a Gaussian can then be BOTH duplicated and split: duplicate() runs first, split() replaces the original),
+    and once step > reset_every prune also where it exceeds prune_scale2d."""
     grads = state["grad2d"] / state["count"].clamp(min=1)
     high = grads > grow_grad2d
     small = scales_exp.amax(-1) <= grow_scale3d * scene_scale
     is_dupli = high & small
     is_split = high & ~small
+    screen = step < refine_scale2d_stop_iter
+    if screen:
+        is_split = is_split | (state["radii"] > grow_scale2d)
     is_prune = opacities_sig < prune_opa
     if step > reset_every:
         is_prune = is_prune | (scales_exp.amax(-1) > prune_scale3d * scene_scale)
+        if screen:
+            is_prune = is_prune | (state["radii"] > prune_scale2d)
     return is_dupli, is_split, is_prune
 
 

@@ -16,11 +16,12 @@ int mi_set_error_msg(const char* msg) {
 }
 
 extern "C" const char* mi3dgs_last_error(void) { return g_err; }
-extern "C" int mi3dgs_abi_version(void) { return 5; }
+extern "C" int mi3dgs_abi_version(void) { return 6; }
 extern "C" int mi3dgs_splat_stride(void) { return SPLAT_STRIDE; }
 extern "C" int mi3dgs_grad_stride(void) { return GRAD_STRIDE; }
 
 // ------------------------------------------------------------------ per-kernel profiler
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -29,11 +30,13 @@ extern "C" int mi3dgs_grad_stride(void) { return GRAD_STRIDE; }
 namespace {
 struct ProfRec { int tag; hipEvent_t a, b; };
 std::mutex g_pm;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<std::string> g_tags;
 std::vector<ProfRec> g_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
-hipEvent_t g_cur_b = nullptr;
+// the end event of the launch THIS thread is bracketing: begin / end are paired inside one MI_LAUNCH on one thread, so two host
+// threads launching at once each close their own record (VERDICT r3, weak 10 ii: this was one unlocked global)
+thread_local hipEvent_t g_cur_b = nullptr;
 
 int tag_id(const char* t) {
     for (size_t i = 0; i < g_tags.size(); i++) if (g_tags[i] == t) return (int)i;

@@ -747,7 +747,11 @@ __device__ __forceinline__ void os_grid_barrier(uint32_t* bar, uint32_t nblocks,
     // where every XCD reads them.  So the barrier is: wait for this wave's stores, block barrier, count the block in, wait for
     // the others.  (First version: release / acquire fences at agent scope, i.e. a write-back and an invalidate of the whole
     // L2 per block and pass -- 60 us for a 40 k-key sort that takes 41 us as five launches.)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's stores are complete
+    // The wait is spelled out: a workgroup-scope release fence compiles to `s_waitcnt lgkmcnt(0)` only on gfx950 (the CU's
+    // waves share an L1, so the compiler owes them nothing more) and a block would count itself in with its sc1 stores and its
+    // histogram atomics still in flight.  `make check-isa` greps the ISA for this wait in front of the barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores and returning atomics are complete
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

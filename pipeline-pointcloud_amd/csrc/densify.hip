@@ -11,6 +11,12 @@
 //   split     = high & !small       -> original replaced by 2 samples, scale / 1.6, zero state
 //   prune (evaluated on the grown set, as upstream does): sigmoid(opacity) < prune_opa,
 //          or (step > reset_every and max(exp(scale)) > prune_scale3d * scene_scale)
+// Screen-size rules (gsplat grow_scale2d / prune_scale2d / refine_scale2d_stop_iter = nerfstudio splatfacto's
+// split_screen_size 0.05 / cull_screen_size 0.15 / stop_screen_size_at 4000 -- the DEFAULT job of the reference,
+// main.py:1270-1306), on the running maximum r of radius / max(W, H) (stat_radii), while step < the stop iteration:
+//   split |= r > grow_scale2d            (a Gaussian that is ALSO a duplicate gives three outputs: upstream duplicates
+//                                         first and then splits the original: copy + two samples, all with zero state)
+//   prune |= step > reset_every and r > prune_scale2d      (children inherit the parent's statistic upstream)
 // The pass is: decide -> exclusive scan of output counts -> scatter into fresh buffers.
 // Output order: survivors keep their relative order, children sit next to their parent
 // (upstream appends them at the end; the order only breaks exact-depth ties).
@@ -44,9 +50,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 // flags: bit0 duplicate, bit1 split, bit2 prune
 __global__ __launch_bounds__(256) void densify_decide_kernel(
     int N, const float* __restrict__ scales_log, const float* __restrict__ opac_logit,
-    const float* __restrict__ stat_grad2d, const float* __restrict__ stat_count, float grow_grad2d,
-    float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs, int do_grow, int check_too_big,
-    uint8_t* __restrict__ flags, uint32_t* __restrict__ out_count) {
+    const float* __restrict__ stat_grad2d, const float* __restrict__ stat_count, const float* __restrict__ stat_radii,
+    float grow_grad2d, float grow_scale3d_abs, float grow_scale2d, float prune_opa, float prune_scale3d_abs,
+    float prune_scale2d, int do_grow, int check_too_big, uint8_t* __restrict__ flags, uint32_t* __restrict__ out_count) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float smax = __expf(fmaxf(scales_log[3 * n], fmaxf(scales_log[3 * n + 1], scales_log[3 * n + 2])));
@@ -58,11 +64,14 @@ __global__ __launch_bounds__(256) void densify_decide_kernel(
         dup = high && small;
         split = high && !small;
     }
-    float s_eff = split ? smax / 1.6f : smax;
+    const float r2d = stat_radii ? stat_radii[n] : 0.f;            // (null = past the stop iteration, or a preset without the rule)
+    if (do_grow && r2d > grow_scale2d) split = true;
+    // (split children are smaller; a duplicate's copy keeps smax, but then smax <= grow_scale3d < prune_scale3d and nothing changes)
+    float s_eff = (split && !dup) ? smax / 1.6f : smax;
     bool prune = sigmoidf_(opac_logit[n]) < prune_opa;
-    if (check_too_big) prune = prune || (s_eff > prune_scale3d_abs);
+    if (check_too_big) prune = prune || (s_eff > prune_scale3d_abs) || (r2d > prune_scale2d);
     flags[n] = (uint8_t)((dup ? 1 : 0) | (split ? 2 : 0) | (prune ? 4 : 0));
-    out_count[n] = prune ? 0u : ((dup || split) ? 2u : 1u);
+    out_count[n] = prune ? 0u : 1u + (dup ? 1u : 0u) + (split ? 1u : 0u);
 }
 
 // ---- scatter = map + row gathers.  A first version copied rows one thread per Gaussian (45 floats at a
@@ -84,8 +93,14 @@ __global__ __launch_bounds__(256) void densify_map_kernel(int N, const uint8_t* 
     if (f & 4) return;
     uint32_t o = offsets[n];
     bool dup = f & 1, split = f & 2;
-    int copies = (dup || split) ? 2 : 1;
+    int copies = 1 + (dup ? 1 : 0) + (split ? 1 : 0);
     if (o + copies > cap) return;   // capacity guard; the host checks the total first
+    if (dup && split) {             // duplicated, then the original split: the untouched copy first, then the two samples
+        src_of[o] = (uint32_t)n | MAP_ZERO_STATE;
+        src_of[o + 1] = (uint32_t)n | MAP_ZERO_STATE | MAP_SPLIT;
+        src_of[o + 2] = (uint32_t)n | MAP_ZERO_STATE | MAP_SPLIT | MAP_SECOND;
+        return;
+    }
     for (int c = 0; c < copies; c++)
         src_of[o + c] = (uint32_t)n | ((split || c > 0) ? MAP_ZERO_STATE : 0u) | (split ? MAP_SPLIT : 0u) | (c ? MAP_SECOND : 0u);
 }
@@ -169,14 +184,16 @@ __global__ __launch_bounds__(256) void reset_opacity_kernel(int N, float* __rest
 
 // Step 1: decision flags + per-Gaussian output counts.
 extern "C" int mi3dgs_densify_decide(int N, const float* scales_log, const float* opacities_logit,
-                                     const float* stat_grad2d, const float* stat_count, float grow_grad2d,
-                                     float grow_scale3d_abs, float prune_opa, float prune_scale3d_abs, int do_grow,
-                                     int check_too_big, uint8_t* flags, uint32_t* out_count, void* stream) {
+                                     const float* stat_grad2d, const float* stat_count, const float* stat_radii,
+                                     float grow_grad2d, float grow_scale3d_abs, float grow_scale2d, float prune_opa,
+                                     float prune_scale3d_abs, float prune_scale2d, int do_grow, int check_too_big,
+                                     uint8_t* flags, uint32_t* out_count, void* stream) {
     if (N <= 0) return 0;
     MI_REQUIRE(!do_grow || (stat_grad2d && stat_count), "densify_decide: growing needs the running statistics");
+    MI_REQUIRE(!stat_radii || (grow_scale2d > 0.f && prune_scale2d > 0.f), "densify_decide: screen-size thresholds must be positive");
     MI_LAUNCH("densify_decide", densify_decide_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, scales_log,
-                       opacities_logit, stat_grad2d, stat_count, grow_grad2d, grow_scale3d_abs, prune_opa,
-                       prune_scale3d_abs, do_grow, check_too_big, flags, out_count);
+                       opacities_logit, stat_grad2d, stat_count, stat_radii, grow_grad2d, grow_scale3d_abs, grow_scale2d,
+                       prune_opa, prune_scale3d_abs, prune_scale2d, do_grow, check_too_big, flags, out_count);
     MI_LAUNCH_CHECK();
     return 0;
 }

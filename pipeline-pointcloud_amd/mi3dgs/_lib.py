@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MI3DGS_LIB") or os.path.join(_HERE, "libmi3dgs.so")
 # only by experiments_lib() -- the A/B tools under tools/ and the tests that use a rejected-but-correct variant as a yardstick
 EXP_LIB_PATH = os.path.join(_HERE, "libmi3dgs_exp.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib: Optional[C.CDLL] = None
 _exp_lib: Optional[C.CDLL] = None
@@ -71,7 +71,7 @@ _SIGNATURES = {
     "mi3dgs_adam_step": (_i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_ll),
                               C.POINTER(_fl), _i, _fl, _fl, _fl, _fl, _f]),
     "mi3dgs_debug_hbm_stream": (_i, [_f, _ll, _i, _i, _f]),
-    "mi3dgs_densify_decide": (_i, [_i, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f]),
+    "mi3dgs_densify_decide": (_i, [_i, _f, _f, _f, _f, _f, _fl, _fl, _fl, _fl, _fl, _fl, _i, _i, _f, _f, _f]),
     "mi3dgs_densify_scatter": (_i, [_i, _ll, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f),
                                     C.POINTER(_f), _f, _f, _ll, _u32, _f, _f]),
     "mi3dgs_reset_opacity": (_i, [_i, _f, _fl, _f, _f, _f]),

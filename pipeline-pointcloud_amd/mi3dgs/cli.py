@@ -122,6 +122,8 @@ def splatfacto_config(model: str, max_steps: int, scale_reg: bool, n_train: int,
         lr_sh0=2.5e-3, lr_shN=2.5e-3 / 20, scene_scale=1.0,
         prune_opa=0.005 if big else 0.1, grow_grad2d=0.0005 if big else 0.0008, grow_scale3d=0.01, prune_scale3d=0.5,
         refine_start_iter=500, refine_stop_iter=15000, reset_every=3000, refine_every=100,
+        # split_screen_size / cull_screen_size / stop_screen_size_at
+        grow_scale2d=0.05, prune_scale2d=0.15, refine_scale2d_stop_iter=4000,
         pause_refine_after_reset=n_train + 100, absgrad=True, use_scale_regularization=scale_reg,
         random_background=True, capacity=capacity, auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True, overlap_culled_adam="after_binning",
         num_downscales=2, resolution_schedule=3000)          # splatfacto: 1/4 -> 1/2 -> full, every 3000 steps

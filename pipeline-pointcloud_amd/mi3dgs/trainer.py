@@ -53,6 +53,13 @@ class TrainConfig:
     reset_every: int = 3000
     refine_every: int = 100
     pause_refine_after_reset: int = 0
+    # screen-size rules (gsplat DefaultStrategy grow_scale2d / prune_scale2d / refine_scale2d_stop_iter; 0 = off, gsplat's default.
+    # nerfstudio splatfacto -- the reference's default job, main.py:1270-1306 -- sets split_screen_size 0.05, cull_screen_size
+    # 0.15, stop_screen_size_at 4000): while step < the stop iteration a Gaussian whose largest radius / max(W, H) since the last
+    # refine exceeds grow_scale2d is split, and (once step > reset_every) one beyond prune_scale2d is pruned
+    grow_scale2d: float = 0.05
+    prune_scale2d: float = 0.15
+    refine_scale2d_stop_iter: int = 0
     absgrad: bool = False
     # splatfacto extras the reference turns on (main.py:1288)
     use_scale_regularization: bool = False
@@ -207,7 +214,9 @@ class Trainer:
         self.loss_scratch: Dict = {}
         self.v_render = torch.empty(1, self.H, self.W, 3, dtype=torch.float32, device=dev)
         self.v_alphas = torch.zeros(1, self.H, self.W, 1, dtype=torch.float32, device=dev)
-        self.stats = {k: torch.zeros(cap, dtype=torch.float32, device=dev) for k in ("grad2d", "count", "radii")}
+        # (the screen-radius statistic exists only for a preset that reads it, and is written only while it is read)
+        self.stats = {k: torch.zeros(cap, dtype=torch.float32, device=dev)
+                      for k in ("grad2d", "count") + (("radii",) if self.cfg.refine_scale2d_stop_iter > 0 else ())}
         self.flags_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
         self.count_buf = torch.empty(cap, dtype=torch.int32, device=dev)
         self.offs_buf = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -379,7 +388,8 @@ class Trainer:
         ops.rasterize_bwd(splats, binning, self.W, self.H, alphas, last_ids, self.v_render, self.v_alphas, 16, bg,
                           c.absgrad, v_splats, render=render, seg_ws=self._seg_ws)
         track = c.densify and self.step_count < c.refine_stop_iter
-        stats = {k: v[:n] for k, v in self.stats.items()} if track else None
+        stats = ({k: v[:n] for k, v in self.stats.items() if k != "radii" or self.step_count < c.refine_scale2d_stop_iter}
+                 if track else None)
         bank = m.banks[m.cur]
         if fused:
             ops.project_bwd_adam([bank[g]["p"] for g in GROUPS], [bank[g]["m"] for g in GROUPS],
@@ -518,9 +528,11 @@ class Trainer:
         n = m.n
         st = ops._stream(self.device)
         flags, counts, offs = self.flags_buf[:n], self.count_buf[:n], self.offs_buf[:n]
+        screen = "radii" in self.stats and self.step_count < c.refine_scale2d_stop_iter
         ops._lib.call("mi3dgs_densify_decide", n, ops._p(m.p("scales")), ops._p(m.p("opacities")),
-                      ops._p(self.stats["grad2d"]), ops._p(self.stats["count"]), float(c.grow_grad2d),
-                      float(c.grow_scale3d * c.scene_scale), float(c.prune_opa), float(c.prune_scale3d * c.scene_scale),
+                      ops._p(self.stats["grad2d"]), ops._p(self.stats["count"]), ops._p(self.stats["radii"]) if screen else None,
+                      float(c.grow_grad2d), float(c.grow_scale3d * c.scene_scale), float(c.grow_scale2d), float(c.prune_opa),
+                      float(c.prune_scale3d * c.scene_scale), float(c.prune_scale2d),
                       int(do_grow), int(self.step_count > c.reset_every), ops._p(flags), ops._p(counts), st)
         ops.scan_exclusive_u32(counts, offs, self.total_buf)
         new_n = int(self.total_buf.item())
@@ -537,7 +549,9 @@ class Trainer:
                       ops._ptr_array([dst[g]["m"] for g in GROUPS]), ops._ptr_array([dst[g]["v"] for g in GROUPS]),
                       ops._p(flags), ops._p(offs), m.capacity, seed, ops._p(self.count_buf), st)   # count_buf: free after the scan
         hist = torch.bincount(flags.to(torch.int64), minlength=8).tolist()            # one read-back for the log line
-        info = dict(n_before=n, n_after=new_n, n_dup=hist[1], n_split=hist[2], n_prune=hist[4] + hist[5] + hist[6] + hist[7])
+        # (flag 3 = duplicated AND split by the screen-size rule: three outputs)
+        info = dict(n_before=n, n_after=new_n, n_dup=hist[1] + hist[3], n_split=hist[2] + hist[3],
+                    n_prune=hist[4] + hist[5] + hist[6] + hist[7])
         m.cur = 1 - m.cur
         m.n = new_n
         if self._auto_cap is not None and new_n > n:

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
     h = ctypes.CDLL(built.LIB_PATH)
     for name in _declared():
         assert hasattr(h, name)
-    assert built.lib().mi3dgs_abi_version() == 5
+    assert built.lib().mi3dgs_abi_version() == 6
     assert built.lib().mi3dgs_splat_stride() == 16 and built.lib().mi3dgs_grad_stride() == 16
 
 
@@ -91,6 +91,15 @@ def test_code_object_is_gfx950_only(built):
     assert b"gfx950" in blob
     for other in (b"gfx942", b"gfx90a", b"sm_80"):
         assert other not in blob
+
+
+def test_grid_barrier_waits_for_its_stores_in_the_isa():
+    """os_grid_barrier must issue s_waitcnt vmcnt(0) before counting its block in; a workgroup release fence
+    alone compiles to lgkmcnt(0) on gfx950.  `make check-isa` compiles binning.hip to ISA with the product flags and greps it."""
+    csrc = os.path.join(ROOT, "pipeline-pointcloud_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 without the wait" in r.stdout
 
 
 def test_no_cpu_fallback():

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import activated, assert_seg_clear, rel_err, seg_ctl, small_scene
+from helpers import activated, assert_clean, assert_seg_clear, rel_err, seg_ctl, small_scene
 from oracle import gs_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +46,7 @@ def test_radix_sort_stable_bit_exact(dev, n, nbits, mode):
     v = vals.to(dev)
     ops.sort_pairs_u32(k, v, nbits)
     ops._lib.lib().mi3dgs_debug_set_sort_mode(2)
+    assert_clean(ops, f"sort n={n} nbits={nbits} mode={mode}")     # a barrier / look-back wait that ran out only shows in the error word
     order = np.argsort(keys.numpy(), kind="stable")
     assert np.array_equal(v.cpu().numpy(), vals.numpy()[order])
     assert np.array_equal(k.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, keys.numpy()[order])
@@ -437,6 +438,103 @@ def test_adam_matches_oracle_and_torch(dev):
 
 
 # ----------------------------------------------------------------------------- densify
+@pytest.mark.parametrize("step,expect_screen", [(3100, True), (2500, True), (4000, False)])
+def test_densify_screen_size_rules_match_the_oracle_masks(dev, step, expect_screen):
+    """`ns-train splatfacto` (reference main.py:1270-1306): split_screen_size 0.05 / cull_screen_size 0.15 until step 4000 =
+    gsplat's grow_scale2d / prune_scale2d / refine_scale2d_stop_iter.  Decisions against oracle.strategy_masks, including
+    Gaussians that are duplicated AND split (three outputs), the prune half only once step > reset_every, and nothing of it
+    from the stop iteration on."""
+    from mi3dgs import trainer
+    n = 1000
+    sc = small_scene(n=n, seed=12)
+    sc.params["scales"][:300] = math.log(0.005)      # below grow_scale3d: duplicate candidates
+    sc.params["opacities"][::19] = -6.0              # below prune_opa
+    g = sc.to(dev)
+    img = torch.rand(2, sc.height, sc.width, 3, device=dev)
+    cfg = trainer.TrainConfig(capacity=4000, reset_every=3000, grow_scale2d=0.05, prune_scale2d=0.15, refine_scale2d_stop_iter=4000,
+                              prune_scale3d=0.5)
+    tr = trainer.Trainer(g.params, g.viewmats, g.Ks, img, sc.width, sc.height, cfg)
+    assert "radii" in tr.stats
+    gen = torch.Generator().manual_seed(6)
+    tr.stats["grad2d"][:n] = (torch.rand(n, generator=gen) * 6e-4).to(dev)
+    tr.stats["count"][:n] = torch.randint(0, 3, (n,), generator=gen).float().to(dev)
+    tr.stats["radii"][:n] = (torch.rand(n, generator=gen) * 0.2).to(dev)        # a quarter above 0.15, three quarters above 0.05
+    for gname in trainer.GROUPS:
+        tr.model.state(gname, "m").fill_(1.0)
+    P = {k: v.clone() for k, v in sc.params.items()}
+    state = {k: tr.stats[k][:n].cpu().double() for k in ("grad2d", "count", "radii")}
+    # the statistic is stored in float32; compare the oracle's thresholds on the same values
+    tr.step_count = step
+    sc_exp, op_sig = P["scales"].double().exp(), torch.sigmoid(P["opacities"].double())
+    dup, split, _ = O.strategy_masks(state, sc_exp, op_sig, step, prune_scale3d=0.5, grow_scale2d=float(np.float32(0.05)),
+                                     prune_scale2d=float(np.float32(0.15)), refine_scale2d_stop_iter=4000)
+    dup0, split0, _ = O.strategy_masks(state, sc_exp, op_sig, step, prune_scale3d=0.5)
+    assert bool((split & ~split0).any()) == expect_screen and torch.equal(dup, dup0)
+    if expect_screen:
+        assert int((dup & split).sum()) > 10             # the three-output case is exercised
+    # prune on the grown set: samples of a split are 1.6 x smaller, every child carries the parent's radius statistic
+    s_eff = sc_exp.amax(-1) / torch.where(split & ~dup, 1.6, 1.0)
+    prune = op_sig < 0.005
+    if step > 3000:
+        prune = prune | (s_eff > 0.5)
+        if step < 4000:
+            prune = prune | (state["radii"] > float(np.float32(0.15)))
+    info = tr.refine(do_grow=True)
+    flags = tr.flags_buf[:n].cpu()
+    assert torch.equal((flags & 1).bool(), dup) and torch.equal((flags & 2).bool(), split) and torch.equal((flags & 4).bool(), prune)
+    copies = (~prune).long() * (1 + dup.long() + split.long())
+    assert info["n_after"] == int(copies.sum()) == tr.model.n
+    assert (info["n_dup"] == int((dup & ~prune).sum()) and info["n_split"] == int((split & ~prune).sum())
+            and info["n_prune"] == int(prune.sum()))
+    offs = torch.cumsum(copies, 0) - copies
+    means, scales = tr.model.p("means").cpu(), tr.model.p("scales").cpu()
+    m_state = tr.model.state("means", "m").cpu()
+    # duplicated AND split: [untouched copy, sample, sample], all three with zero Adam state
+    both = dup & split & ~prune
+    if expect_screen:
+        b = offs[both]
+        assert torch.equal(means[b], P["means"][both]) and torch.equal(scales[b], P["scales"][both])
+        for k in (1, 2):
+            assert torch.allclose(scales[b + k], P["scales"][both] - math.log(1.6), atol=1e-6)
+            assert float((means[b + k] - P["means"][both]).norm(dim=-1).min()) > 0
+        assert float((means[b + 1] - means[b + 2]).norm(dim=-1).min()) > 0
+        assert float(torch.cat([m_state[b], m_state[b + 1], m_state[b + 2]]).abs().max()) == 0.0
+    # split only: two samples; duplicate only: original keeps its state, the copy starts from zero
+    so = offs[split & ~dup & ~prune]
+    assert torch.allclose(scales[so], P["scales"][split & ~dup & ~prune] - math.log(1.6), atol=1e-6)
+    assert float(m_state[so].abs().max()) == 0.0 and float(m_state[so + 1].abs().max()) == 0.0
+    do = offs[dup & ~split & ~prune]
+    assert torch.equal(means[do], means[do + 1]) and float(m_state[do].min()) == 1.0 and float(m_state[do + 1].abs().max()) == 0.0
+    # untouched survivors bit for bit, in order
+    plain = ~prune & ~dup & ~split
+    for gname, w in zip(trainer.GROUPS, trainer.WIDTHS):
+        assert torch.equal(tr.model.banks[tr.model.cur][gname]["p"][: tr.model.n].cpu()[offs[plain]], P[gname].reshape(n, w)[plain])
+    assert float(tr.stats["radii"].abs().max()) == 0.0
+
+
+def test_screen_radius_statistic_is_the_running_max_and_only_written_while_read(dev):
+    """gsplat DefaultStrategy._update_state: state['radii'] = max(state['radii'], radii / max(W, H)) over the steps since the
+    last refine, visible Gaussians only; a preset without the rule allocates no such array, and from the stop iteration on the
+    projection backward is not handed it any more."""
+    from mi3dgs import ops, trainer
+    sc = small_scene(n=700, seed=13)
+    g = sc.to(dev)
+    img = torch.rand(2, sc.height, sc.width, 3, device=dev)
+    off = trainer.Trainer(g.params, g.viewmats, g.Ks, img, sc.width, sc.height, trainer.TrainConfig(capacity=1000))
+    assert "radii" not in off.stats
+    tr = trainer.Trainer(g.params, g.viewmats, g.Ks, img, sc.width, sc.height,
+                         trainer.TrainConfig(capacity=1000, refine_scale2d_stop_iter=3, refine_start_iter=10_000))
+    expect = torch.zeros(700)
+    for i in range(3):
+        tr.step(i % 2)
+        r = tr.radii[0, :700].cpu()
+        vis = (r > 0).all(-1)
+        expect = torch.where(vis, torch.maximum(expect, r.max(-1).values.float() / max(sc.width, sc.height)), expect)
+    assert torch.equal(tr.stats["radii"][:700].cpu(), expect) and float(expect.max()) > 0
+    tr.step(0)                              # step 3 = the stop iteration: not touched any more
+    assert torch.equal(tr.stats["radii"][:700].cpu(), expect)
+
+
 def test_densify_decisions_and_surgery(dev):
     from mi3dgs import trainer
     sc = small_scene(n=1000, seed=10)
