@@ -3,6 +3,7 @@
 // main.py:1312 / main.py:1343.  Built with -fno-slp-vectorize (see the Makefile).
 #include "rasterize_mfma.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mfma_raster {
 
@@ -25,6 +26,20 @@ namespace mfma_raster {
 // groups (6..8 hi, 9..11 lo) whose sums land on the same three slots.  4 x v_mfma_f32_16x16x32_bf16 (64 matrix-pipe cycles)
 // per chunk replace the five moment multiplies and the 24-instruction cross-lane reduce-scatter of every live visit.
 // With ABSGRAD the two |.| sums ride along as two more rows per splat (chunks of 4).
+//
+// Round 4 (same-box A/B of every step with tools/raster_ab.py, profiles/r04_raster_bwd_steps.txt; S2 plain 369 -> 308 us, with
+// absgrad 573 -> 471, S1 119 -> 99, wolf 960 x 720 with absgrad 151 -> 122):
+//   * the chain carries bd = (colour behind the splat) . v_rgb - tail and forms q = (alpha ra) (T cv - bd);
+//   * a splat's colour (and, with ABSGRAD, the five numbers of d sigma / d(mx, my) as forms in (u, v)) is read ONCE per sub-batch,
+//     lane l holding splat l's, and handed to the visits by v_readlane: the wave-uniform LDS read per visit queued behind the two
+//     stores of the visit before it (LDS serves a wave in order) and every visit's block waited for it;
+//   * the rows of one splat are adjacent (row = kinds x splat + kind): a visit's words leave as ds_write2_b32 and a lane of the
+//     accumulator holds ONE splat's sums (one cross-lane step instead of four in the ABSGRAD merge, half the stores);
+//   * a sub-batch whose 32 splats all have opacity < 0.998, in a wave all of whose pixels composited something, runs an instance
+//     without the 0.999 clamp and without the `has` mask (no v_min, no clamp compare, no select on q);
+//   * the group flush gives every slot ONE lane (flush_group_lane_per_slot).  Timing probes had priced the old flush's
+//     arithmetic at 70 us of S2's 354 -- its atomics at nothing, its two barriers at 7;
+//   * ABSGRAD rebuilds the alpha basis in front of every sub-batch instead of holding its ten registers across the visits.
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
@@ -33,28 +48,24 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int TR_STRIDE = 68;
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
+constexpr int AW = 12;                    // floats per (wave, slot) sum row: 48 bytes, read by the flush as three float4
 // ---- two shapes of the kernel, chosen per launch by the number of Gaussians (mi_rasterize_bwd_mm):
 //   STG        splats per staged batch: 256 (one per thread) or 128 (LDS 50 -> 40 KB: room for four blocks per CU)
 //   PIPELINE   true: a chunk's contraction is issued one MFMA per visit among the NEXT chunk's visits (16 + 4 more live
 //              registers); false: operands are read and the four MFMAs issued when the chunk ends
-//   COL_AHEAD  the wave-uniform colour read runs this many visits ahead (3 registers each)
-//   WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 126)
-// DEEP = the round-2 kernel: fastest per wave, three waves per SIMD.  WIDE: 126 registers, 40 KB, four waves per SIMD.
+//   WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128)
+// DEEP = the round-2 kernel: fastest per wave, three waves per SIMD.  WIDE: 128 registers, 40 KB, four waves per SIMD.
 // Same-box A/B (profiles/r03_raster_bwd_shape_ab.txt, tools/raster_ab.py): S2 (2 M Gaussians, every tile a few hundred
 // reached splats) 459 -> 398 us with WIDE; S1 148 -> 144; the reference's wolf.spz at 960 x 720 (100 k Gaussians, the time is the
 // serial walk of a few hundred heavy tiles) 201 -> 205, with absgrad 271 -> 288: there a wave's own speed counts, not how many
 // waves wait beside it.  WIDE by the compiler's spiller instead (pipelining kept, 39 registers in scratch) LOST 8 - 15 %
 // (r03_raster_bwd_occupancy_ab.txt); WIDE's ingredients at three waves (no pipelining, 256-slot batches) lose 3 - 5 %.
-struct ShapeDeep { static constexpr int STG = 256, COL_AHEAD = 2, WAVES = 3; static constexpr bool PIPELINE = true; };
-struct ShapeWide { static constexpr int STG = 128, COL_AHEAD = 1, WAVES = 4; static constexpr bool PIPELINE = false; };
-// columns of a per-wave sum row: the nine of the reduce-scatter kernel, then the lo part of the colour sums (9..11; the flush adds
-// them), then |x|, |y|.  MERGE (ABSGRAD at four waves per SIMD, where the LDS has to stay under 40 KB): the lo colour sums
-// are added to the hi ones before they are stored (three lanes of the accumulator, one cross-lane read each) and |x|, |y| take
-// columns 9, 10: eleven columns instead of fourteen.
-template <typename SH> struct AbsCols {
-    static constexpr bool MERGE = SH::WAVES >= 4;
-    static constexpr int ABSX = MERGE ? 9 : 12, ABSY = MERGE ? 10 : 13;
-};
+struct ShapeDeep { static constexpr int STG = 256, WAVES = 3; static constexpr bool PIPELINE = true; };
+struct ShapeWide { static constexpr int STG = 128, WAVES = 4; static constexpr bool PIPELINE = false; };
+// columns of a per-wave sum row: the nine of the reduce-scatter kernel (AC_*), then, without ABSGRAD, the lo part of the colour
+// sums (9..11; the flush adds them); with ABSGRAD the lo colour sums are added to the hi ones before they are stored (one DPP
+// step in mm_finish) and |x|, |y| take columns 9, 10.
+constexpr int ABS_COL_X = 9, ABS_COL_Y = 10;
 
 // LDS float atomics are lane-serial on this part (tools/micro/lds_ops.hip: ds_add_f32 takes ~3 LDS cycles per ACTIVE lane,
 // 55 for the 18 lanes that would add a chunk's sums, against 3 for a plain ds_write_b32), so every wave keeps its own sums
@@ -62,21 +73,24 @@ template <typename SH> struct AbsCols {
 template <bool ABSGRAD, typename SH>
 struct StagedBwdMM {
     static constexpr int STG = SH::STG;
-    static constexpr int AW = ABSGRAD ? (AbsCols<SH>::MERGE ? 11 : 14) : 12;
-    StagedN<STG> f;
+    StagedN<STG> f;           // (the Gaussian's index rides in the fourth word of its colour record, f.uni[slot].w)
     float4 geo[STG];          // mx, my (relative to the tile centre), A, B
-    float2 geo2[STG];         // C, 1 / o
-    int id[STG];
-    float accw[4][GRP][AW];
-    alignas(16) unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (value, splat of the chunk), columns = the wave's 64 pixels
+    // C, 1 / o [, ax = A mx + B my, ay = B mx + C my: the constant terms of d sigma / d(mx, my) as forms in (u, v)]
+    typename std::conditional<ABSGRAD, float4, float2>::type geo2[STG];
+    alignas(16) float accw[4][GRP][AW];
+    alignas(16) unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (splat of the chunk, value), columns = the wave's 64 pixels
+    unsigned hot[STG / SUB];            // per sub-batch: some splat's opacity is >= 0.998 (the alpha clamp at 0.999 can be active)
     unsigned long long gmask[4];        // per wave: slots of the current group whose visit was live (its sums are meaningful)
     int wave_max[4];
 };
 
+template <typename LT>
+__device__ __forceinline__ int slot_id(const LT& L, int slot) { return reinterpret_cast<const int*>(&L.f.uni[slot])[3]; }
+
 // what a lane does with the accumulator of a chunk: D row 4 (lane >> 4) + r, column lane & 15
 struct MMLane {
     u4v bop[4];               // B operand of MFMA m: column (lane & 15) at the pixels 16 m + 4 (lane >> 4) + 0..3, both parts
-    int acc_off;              // float offset of this lane's (first row, column) inside a chunk of accw, or -1: nothing to store
+    int acc_off;              // float offset of this lane's column inside the sum row of its (first) splat of a chunk, or -1: nothing to store
 };
 
 __device__ __forceinline__ unsigned f32_hi(float v) { return __builtin_bit_cast(unsigned, v) & 0xFFFF0000u; }
@@ -90,9 +104,18 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& wa, unsigned&
     wb = hb | (l >> 16);
 }
 
-// three terms (experiments build, A/B of VERDICT r2 #3): hi and mid are exact truncations, lo is rounded -- 24 significant bits.
-// Word A = hi | mid, word B = lo | 0; both multiply the same basis, so the two words are two more ROWS of the same product
-// whose results add up.
+// the same for |a|, |b|: the mask that takes the hi part drops the sign with it
+__device__ __forceinline__ void split2_abs(float a, float b, unsigned& wa, unsigned& wb) {
+    const unsigned ha = __builtin_bit_cast(unsigned, a) & 0x7FFF0000u, hb = __builtin_bit_cast(unsigned, b) & 0x7FFF0000u;
+    const f2v r = {__builtin_fabsf(a) - __builtin_bit_cast(float, ha), __builtin_fabsf(b) - __builtin_bit_cast(float, hb)};
+    const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2v));
+    wa = ha | (l & 0xFFFFu);
+    wb = hb | (l >> 16);
+}
+
+// three terms (experiments build, the precision A/B of VERDICT r2 #3 / r3 #4): hi and mid are exact truncations, lo is rounded --
+// 24 significant bits.  Word A = hi | mid, word B = lo | 0; both multiply the same basis, so the two words are two more ROWS of
+// the same product whose results add up.
 __device__ __forceinline__ void split3w(float a, unsigned& wA, unsigned& wB) {
 #pragma clang fp contract(off)
     const unsigned h = f32_hi(a);
@@ -105,16 +128,14 @@ __device__ __forceinline__ void split3w(float a, unsigned& wA, unsigned& wB) {
     wB = l;
 }
 
-// The contraction of a chunk is software-pipelined against the visits of the NEXT chunk: its A operands are read when its last
-// visit has stored (LDS executes a wave's instructions in order, so the next chunk's stores to the same rows stay behind these
-// reads), its 4 MFMAs are issued one per visit between the vector instructions of the following visits, and its
+// DEEP: the contraction of a chunk is software-pipelined against the visits of the NEXT chunk: its A operands are read when its
+// last visit has stored (LDS executes a wave's instructions in order, so the next chunk's stores to the same rows stay behind
+// these reads), its 4 MFMAs are issued one per visit between the vector instructions of the following visits, and its
 // sums are stored when that chunk ends.  At a sub-batch boundary a pending chunk has its operands and none of its MFMAs.
 struct MMPend {
     u4v a[4];
     f4v d;
     int slot0;                // first slot of the chunk inside its group
-    int slot_abs;             // ... inside the staged batch (wave-flush variant)
-    unsigned live;            // ... which of its visits were live (wave-flush variant)
     bool on;                  // wave-uniform
 };
 
@@ -122,62 +143,32 @@ __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
     P.d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, P.a[m]), __builtin_bit_cast(bf8v, mm.bop[m]), P.d, 0, 0, 0);
 }
 
-// WF (variant, MI3DGS_RASTER_MODE=14): the wave turns its own chunk's sums into gradient records and adds them to global
-// memory itself -- no per-wave sums kept for a block flush, no group barriers, but one 64-byte float-atomic request per
-// (quadrant, splat) instead of one per (tile, splat).
-template <bool ABSGRAD, bool WF, bool T3, typename SH>
-__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane,
-                                          float* __restrict__ v_splats) {
-    constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
-    constexpr int CH = (ABSGRAD || T3) ? 4 : 8;
-    if (T3) {          // rows 8..15 (lanes 32..63) hold the sums of the third term: add them to rows 0..7
+// Row layout of a chunk (T3 = the three-term experiment keeps the round-3 layout, kind-major):
+//   plain:    row 2 c + kind,  kind = Q, W             -> D row 4 g + r is splat 2 g + (r >> 1), kind r & 1
+//   ABSGRAD:  row 4 c + kind,  kind = Q, W, |x|, |y|   -> D row 4 g + r is splat g, kind r
+template <bool ABSGRAD, bool T3, typename SH>
+__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
+    const int j = lane & 15;
+    float* a = &L.accw[wv][P.slot0][0];
+    if (T3) {
+        // rows Q 0..3, W 4..7 (words hi | mid), Q 8..11, W 12..15 (words lo | 0): rows 8..15 (lanes 32..63) onto rows 0..7
 #pragma unroll
         for (int r = 0; r < 4; r++) P.d[r] += __shfl_down(P.d[r], 32, 64);
-    }
-    if (ABSGRAD && AbsCols<SH>::MERGE) {     // colour sums: column j + 3 (from the lo part of v_rgb) onto column j = 6..8 (row_shl:3 inside the 16-lane row)
-        const bool col = (lane & 15) >= 6 && (lane & 15) < 9;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float up = __shfl_down(P.d[r], 3, 64);          // lane j + 3 of the same 16-lane row (j <= 8)
-            P.d[r] += col ? up : 0.f;
-        }
-    }
-    if (mm.acc_off >= 0) {
-        float* a = &L.accw[wv][WF ? 0 : P.slot0][0] + mm.acc_off;
-        a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3];
+        if (mm.acc_off >= 0) { a += mm.acc_off; a[0] = P.d[0]; a[AW] = P.d[1]; a[2 * AW] = P.d[2]; a[3 * AW] = P.d[3]; }
+    } else if (ABSGRAD) {
+        // colour sums: column j + 3 (from the lo part of v_rgb) onto column j = 6..8, lane j + 3 of the same 16-lane row: DPP
+        // row_shl:3 (a __shfl_down is a ds_bpermute, an LDS round trip per chunk).  (The element is copied out first:
+        // __builtin_bit_cast applied directly to `P.d[1]` reads element 0 with this clang.)
+        const float d1 = P.d[1];
+        const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d1), 0x103, 0xF, 0xF, true));
+        const float w1 = d1 + ((j >= 6 && j < 9) ? up : 0.f);
+        if (mm.acc_off >= 0) a[mm.acc_off] = j < 6 ? P.d[0] : w1;
+        if (j == 5) { a[mm.acc_off - 5 + ABS_COL_X] = P.d[2]; a[mm.acc_off - 5 + ABS_COL_Y] = P.d[3]; }      // column 5 = the plain sums
+    } else if (mm.acc_off >= 0) {
+        a[mm.acc_off] = j < 6 ? P.d[0] : P.d[1];
+        a[mm.acc_off + AW] = j < 6 ? P.d[2] : P.d[3];
     }
     P.on = false;
-    if (WF) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // same-wave LDS hand-off
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < CH / 4; q++) {
-            const int sc = 4 * q + (lane >> 4), comp = lane & 15;
-            const bool lv = (P.live >> sc) & 1u;
-            if (lv && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
-                const float* ac = L.accw[wv][sc];
-                const int slot = P.slot_abs + sc;
-                const float M = ac[AC_Q], Mu = ac[AC_QU], Mv = ac[AC_QV];
-                const float4 ge = L.geo[slot];
-                const float2 g2 = L.geo2[slot];
-                const float mx = ge.x, my = ge.y;
-                const float sdx = mx * M - Mu, sdy = my * M - Mv;
-                float val;
-                switch (comp) {
-                    case GR_X: val = -(ge.z * sdx + ge.w * sdy); break;
-                    case GR_Y: val = -(ge.w * sdx + g2.x * sdy); break;
-                    case GR_CA: val = -0.5f * (mx * (mx * M - 2.f * Mu) + ac[AC_QUU]); break;
-                    case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + ac[AC_QUV]); break;
-                    case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + ac[AC_QVV]); break;
-                    case GR_OPA: val = M * g2.y; break;
-                    case GR_R: case GR_G: case GR_B: val = (ABSGRAD && AbsCols<SH>::MERGE) ? ac[comp] : ac[comp] + ac[comp + 3]; break;
-                    case GR_ABSX: val = ac[AbsCols<SH>::ABSX < AW ? AbsCols<SH>::ABSX : 0]; break;
-                    default: val = ac[AbsCols<SH>::ABSY < AW ? AbsCols<SH>::ABSY : 0]; break;
-                }
-                atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
-            }
-        }
-    }
 }
 
 template <bool ABSGRAD, typename SH>
@@ -191,30 +182,46 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, 
     P.on = true;
 }
 
-template <bool ABSGRAD, bool WF, bool T3, typename SH>
-__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane,
-                                         float* __restrict__ v_splats) {
+template <bool ABSGRAD, bool T3, typename SH>
+__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
     if (!P.on) return;
 #pragma unroll
     for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
-    mm_finish<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);
+    mm_finish<ABSGRAD, T3, SH>(L, P, mm, wv, lane);
+}
+
+// what lane l holds of splat (l & 31) of the sub-batch: handed to the visits by v_readlane
+struct SubUni { float r, g, b; float A, B, C, ax, ay; };
+
+__device__ __forceinline__ float lane_bcast(float v, int i) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
+
+template <bool ABSGRAD, typename SH>
+__device__ __forceinline__ SubUni load_sub_uni(const StagedBwdMM<ABSGRAD, SH>& L, int sb, int lane) {
+    SubUni U = {};
+    const int k = sb * SUB + (lane & 31);
+    const float4 c = L.f.uni[k];
+    U.r = c.x; U.g = c.y; U.b = c.z;
+    if constexpr (ABSGRAD) {
+        const float4 ge = L.geo[k], g2 = L.geo2[k];
+        U.A = ge.z; U.B = ge.w; U.C = g2.x; U.ax = g2.z; U.ay = g2.w;
+    }
+    return U;
 }
 
 // One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
-// FAST: every pixel of the wave that composited anything is already in range (index <= its last contributor).
-// gbit0: bit of this sub-batch's first chunk in the group's mask.
-template <bool ABSGRAD, bool FAST, int EXP, typename SH>
+// FAST: every pixel of the wave composited something and is already in range (index <= its last contributor), and none of the
+// sub-batch's splats can reach the 0.999 clamp (the caller's test): a visit's membership test is the threshold compare alone.
+template <bool ABSGRAD, bool FAST, bool T3_, typename SH>
 __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
                                                  int bin_final, unsigned long long has, const PixelBasis& px, const MMLane& mm,
-                                                 MMPend& P, unsigned long long& gmask, const float (&vrgb)[3], float tail,
-                                                 float& T, float& bufdot, float* __restrict__ v_splats) {
-    constexpr bool WF = (EXP & 4) != 0;
-    constexpr bool T3 = (EXP & 8) != 0 && !ABSGRAD;      // three-term transport (experiments build)
+                                                 MMPend& P, unsigned long long& gmask, const float (&vrgb)[3],
+                                                 float& T, float& bd, const SubUni& U) {
+    constexpr bool T3 = T3_ && !ABSGRAD;         // three-term transport (experiments build)
     constexpr int CH = (ABSGRAD || T3) ? 4 : 8;  // splats per chunk: CH x (2 or 4 values) = 16 rows
+    constexpr int KINDS = 16 / CH;
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
-    const lds_f4_ptr uni = opaque_lds_base(&L.f.uni[sb * SUB]);
-    // colours two visits ahead: LDS serves a wave in order, so a read queues behind the two stores of the visit before it
-    Rgb col_next = lds_rgb(uni, 0), col_next2 = lds_rgb(uni, SH::COL_AHEAD == 2 ? 1 : 0);
     unsigned* trw = &L.tr[wv][0][lane];
     // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
     // bookkeeping counts like vector work.  A dead visit is a compare and a branch: its rows keep whatever they held, the
@@ -225,60 +232,62 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, co
     for (int i = 0; i < SUB; i++) {
         const int k = sb * SUB + i;
         const int ci = i % CH;
-        const Rgb col = (EXP & 2) ? Rgb{0.3f, 0.4f, 0.5f} : col_next;
-        if (!(EXP & 2)) {
-            if (SH::COL_AHEAD == 2) { col_next = col_next2; col_next2 = lds_rgb(uni, i + 2); }
-            else col_next = lds_rgb(uni, i + 1);
-        }
         if (SH::PIPELINE && ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
         // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
-        unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & has;
-        if (!FAST) valid &= mask_ge_i(bin_final, be - k);
+        unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD);
+        if (!FAST) valid &= has & mask_ge_i(bin_final, be - k);
         if (valid != 0ull) {
             live |= 1u << i;
-            const float alpha = alpha_of(s[i]);
-            // branch-free live part: a lane that does not take part runs it with alpha = 0 (ra = 1, T and bufdot
-            // unchanged bit for bit, both rows 0)
+            const Rgb col = {lane_bcast(U.r, i), lane_bcast(U.g, i), lane_bcast(U.b, i)};
+            const float alpha = FAST ? __builtin_amdgcn_exp2f(s[i]) : alpha_of(s[i]);
+            // branch-free live part: a lane that does not take part runs it with alpha = 0 (ra = 1, T and bd unchanged bit for
+            // bit, both rows 0)
             const float a_eff = lane_of(valid) ? alpha : 0.f;
             const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+            const float cv = col.x * vrgb[0] + col.y * vrgb[1] + col.z * vrgb[2];            // c . v_rgb
+            // v_alpha = T_i cv - ra bd = ra (T cv - bd) with the T BEHIND the splat; q = o vis dL/dalpha = -dL/dsigma = (alpha ra)
+            // (T cv - bd), zero where the 0.999 clamp is active (alpha == o vis otherwise)
+            float w = __builtin_fmaf(T, cv, -bd);
+            // (w before the updates: T and bd are then updated in place; left to itself hipcc forms the new T first and pays a
+            //  register copy for each of the two at the end of the visit)
+            asm volatile("" : "+v"(w), "+v"(T), "+v"(bd));
             T *= ra;
             const float fac = a_eff * T;
-            const float cv = col.x * vrgb[0] + col.y * vrgb[1] + col.z * vrgb[2];            // c . v_rgb
-            const float v_alpha = T * cv - ra * (bufdot - tail);
-            bufdot = __builtin_fmaf(cv, fac, bufdot);
-            // q = o vis dL/dalpha = -dL/dsigma; zero where the 0.999 clamp is active (alpha == o vis otherwise)
-            const unsigned long long gon = valid & mask_le(s[i], LOG2_MAX_ALPHA);
-            const float q = lane_of(gon) ? alpha * v_alpha : 0.f;
+            bd = __builtin_fmaf(cv, fac, bd);
+            float q = (a_eff * ra) * w;
+            if (!FAST) q = lane_of(valid & mask_le(s[i], LOG2_MAX_ALPHA)) ? q : 0.f;
             unsigned wq, wf;
             if (T3) {
                 unsigned wq2, wf2;
                 split3w(q, wq, wq2);
                 split3w(fac, wf, wf2);
+                trw[ci * TR_STRIDE] = wq;
+                trw[(CH + ci) * TR_STRIDE] = wf;
                 trw[(2 * CH + ci) * TR_STRIDE] = wq2;
                 trw[(3 * CH + ci) * TR_STRIDE] = wf2;
             } else {
                 split2(q, fac, wq, wf);
+                trw[KINDS * ci * TR_STRIDE] = wq;
+                trw[(KINDS * ci + 1) * TR_STRIDE] = wf;
             }
-            trw[ci * TR_STRIDE] = wq;
-            trw[(CH + ci) * TR_STRIDE] = wf;
-            if (ABSGRAD) {
-                const float4 ge = L.geo[k];
-                const float cC = L.geo2[k].x;
-                const float dx = ge.x - px.u, dy = ge.y - px.v;
+            if constexpr (ABSGRAD) {
+                // d sigma / d(mx, my) = (A dx + B dy, B dx + C dy) = (ax - A u - B v, ay - B u - C v)
+                // (one scalar operand per instruction: a second one costs a v_mov)
+                const float sB = lane_bcast(U.B, i);
+                const float lx = lane_bcast(U.ax, i) - __builtin_fmaf(lane_bcast(U.A, i), px.u, sB * px.v);
+                const float ly = lane_bcast(U.ay, i) - __builtin_fmaf(lane_bcast(U.C, i), px.v, sB * px.u);
                 unsigned wx, wy;
-                split2(fabsf(q * (ge.z * dx + ge.w * dy)), fabsf(q * (ge.w * dx + cC * dy)), wx, wy);
-                trw[(2 * CH + ci) * TR_STRIDE] = wx;
-                trw[(3 * CH + ci) * TR_STRIDE] = wy;
+                split2_abs(q * lx, q * ly, wx, wy);
+                trw[(KINDS * ci + 2) * TR_STRIDE] = wx;
+                trw[(KINDS * ci + 3) * TR_STRIDE] = wy;
             }
         }
         if (ci == CH - 1) {
-            if (SH::PIPELINE && P.on) mm_finish<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);
+            if (SH::PIPELINE && P.on) mm_finish<ABSGRAD, T3, SH>(L, P, mm, wv, lane);
             const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
             if (cl) {
                 mm_read<ABSGRAD, SH>(L, P, wv, lane, gs0 + i - (CH - 1));
-                P.slot_abs = k - (CH - 1);
-                P.live = cl;
-                if (!SH::PIPELINE) mm_drain<ABSGRAD, WF, T3, SH>(L, P, mm, wv, lane, v_splats);      // read, four MFMAs, store: nothing stays live
+                if (!SH::PIPELINE) mm_drain<ABSGRAD, T3, SH>(L, P, mm, wv, lane);      // read, four MFMAs, store: nothing stays live
             }
         }
     }
@@ -298,16 +307,91 @@ namespace mfma_raster {
 #define RB_STAMP(i, v) do { } while (0)
 #endif
 
+// The flush of one group of 64 slots; wave w takes the slots 16 w .. 16 w + 15.  ONE lane per slot adds the quadrants' sum rows
+// (three 128-bit reads each; quadrant 0 first), forms the gradient components with straight-line code and leaves them in the
+// wave's own transposition rows (free between two chunks); the float atomics then go out sixteen lanes per slot, one 64-byte
+// request per (tile, Gaussian).  The gradients of (x, y, conic A, B, C, opacity) follow from the moments about the tile centre:
+//   sum q dx = mx M - Mu, sum q dx^2 = mx^2 M - 2 mx Mu + Muu, ...   (dx = mx - u, dy = my - v)
+// The flush this replaces (rounds 2, 3) gave every slot sixteen lanes that each summed one column, fetched M, Mu, Mv and a
+// fourth value from their neighbours through ds_bpermute and ran an eleven-way switch on their component: ~120 instructions
+// per round of 16 slots.
+template <bool ABSGRAD, typename SH>
+__device__ __forceinline__ void flush_group_lane_per_slot(StagedBwdMM<ABSGRAD, SH>& L, int wv, int lane, int g0, int bsz,
+                                                          float* __restrict__ v_splats) {
+    constexpr int OUT_STRIDE = 20;            // floats per output row: 16-byte aligned, and 20 l mod 64 keeps eight rows' float4 stores on disjoint banks
+    constexpr int NCOMP = ABSGRAD ? GR_DEPTH : GR_ABSX;
+    const unsigned long long m0 = L.gmask[0], m1 = L.gmask[1], m2 = L.gmask[2], m3 = L.gmask[3];
+    const int sh = 16 * wv;
+    const unsigned f0 = (unsigned)(m0 >> sh) & 0xFFFFu, f1 = (unsigned)(m1 >> sh) & 0xFFFFu, f2 = (unsigned)(m2 >> sh) & 0xFFFFu,
+                   f3 = (unsigned)(m3 >> sh) & 0xFFFFu;
+    unsigned any = f0 | f1 | f2 | f3;
+    const int left = bsz - (g0 + sh);                      // slots of this wave that exist in the batch
+    if (left < 16) any &= left > 0 ? (1u << left) - 1u : 0u;
+    if (any == 0u) return;                                 // wave-uniform
+    float* const out = reinterpret_cast<float*>(&L.tr[wv][0][0]);
+    if (lane < 16 && ((any >> lane) & 1u)) {
+        const int sg = sh + lane;
+        float acc[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) acc[c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned fq = q == 0 ? f0 : q == 1 ? f1 : q == 2 ? f2 : f3;
+            if ((fq >> lane) & 1u) {
+                const float4* row = reinterpret_cast<const float4*>(&L.accw[q][sg][0]);
+                const float4 a = row[0], b = row[1], c = row[2];
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+                acc[8] += c.x; acc[9] += c.y; acc[10] += c.z; acc[11] += c.w;
+            }
+        }
+        const int slot = g0 + sg;
+        const float4 ge = L.geo[slot];
+        const auto g2 = L.geo2[slot];
+        const float mx = ge.x, my = ge.y;
+        const float M = acc[AC_Q], Mu = acc[AC_QU], Mv = acc[AC_QV];
+        const float sdx = mx * M - Mu, sdy = my * M - Mv;                 // sum q dx, sum q dy
+        float4 o0, o1, o2;
+        o0.x = -(ge.z * sdx + ge.w * sdy);                                // GR_X
+        o0.y = -(ge.w * sdx + g2.x * sdy);                                // GR_Y
+        o0.z = -0.5f * (mx * (mx * M - 2.f * Mu) + acc[AC_QUU]);          // GR_CA
+        o0.w = -(mx * (my * M - Mv) - my * Mu + acc[AC_QUV]);             // GR_CB
+        o1.x = -0.5f * (my * (my * M - 2.f * Mv) + acc[AC_QVV]);          // GR_CC
+        o1.y = M * g2.y;                                                  // GR_OPA
+        if (ABSGRAD) {                                                    // (lo colour sums already merged in mm_finish)
+            o1.z = acc[AC_R]; o1.w = acc[AC_G]; o2.x = acc[AC_B];
+            o2.y = acc[ABS_COL_X]; o2.z = acc[ABS_COL_Y];                 // GR_ABSX, GR_ABSY
+        } else {
+            o1.z = acc[AC_R] + acc[AC_R + 3]; o1.w = acc[AC_G] + acc[AC_G + 3]; o2.x = acc[AC_B] + acc[AC_B + 3];
+            o2.y = 0.f; o2.z = 0.f;
+        }
+        o2.w = 0.f;
+        float4* orow = reinterpret_cast<float4*>(out + lane * OUT_STRIDE);
+        orow[0] = o0; orow[1] = o1; orow[2] = o2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // same-wave LDS hand-off (LDS serves a wave in order)
+    __builtin_amdgcn_wave_barrier();
+    const int sl = lane >> 4, comp = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (((any >> (4 * r)) & 15u) == 0u) continue;      // wave-uniform
+        const int s16 = 4 * r + sl;
+        if (((any >> s16) & 1u) && comp < NCOMP)
+            atomicAdd(&v_splats[(size_t)slot_id(L, g0 + sh + s16) * GRAD_STRIDE + comp], out[s16 * OUT_STRIDE + comp]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the rows are rewritten by the next chunk's visits
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One walk of rasterize_bwd: the entries [lo, ...] of tile t's list, back to front, for the block's 256 pixels.
 //   item < 0: the tile's own block -- everything behind the last boundary the forward left (the whole list if it left none);
 //   item >= 0: segment `item` of the work list -- the entries in front of a boundary, state from the forward's checkpoint.
-template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
+template <bool HAS_BG, bool ABSGRAD, bool T3, typename SH>
 __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int item, const SegWs& seg, const float* __restrict__ render,
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
-    constexpr int AW = StagedBwdMM<ABSGRAD, SH>::AW;
     constexpr int STG = SH::STG;
     const bool worker = item >= 0;
     int seg_lo = 0, seg_len = 0;
@@ -320,7 +404,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
-    int lane = lane_id(), wv = threadIdx.x >> 6;  
+    int lane = lane_id(), wv = threadIdx.x >> 6;
     // a segment worker runs this walk in a loop: what depends on the thread alone must be recomputed per walk, not kept in
     // registers across it (hoisted, those values cost 33 - 38 spilled VGPRs)
     asm volatile("" : "+v"(lane), "+v"(wv));
@@ -379,6 +463,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
         bufdot = (r0 - ck.y) * vr0 + (r1 - ck.z) * vr1 + (r2 - ck.w) * vr2 - T_final * bgdot;
         bin_final = end - 1;
     }
+    float bd = bufdot - tail;                   // what the chain carries
     int wmax = bin_final;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
@@ -436,16 +521,13 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the rows are rewritten by the first chunk
         __builtin_amdgcn_wave_barrier();
         // columns of the product: 0..5 moments (AC_QU .. AC_Q), 6..8 colour sums from the hi part of v_rgb, 9..11 from its lo part
-        if (ABSGRAD) {
-            // rows: Q 0..3, W 4..7, |x| 8..11, |y| 12..15  ->  lane group g holds value g of splats r = 0..3
-            mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < (AbsCols<SH>::MERGE ? 9 : 12) ? j : -1) : (j == 5 ? (g == 2 ? AbsCols<SH>::ABSX : AbsCols<SH>::ABSY) : -1);
-        } else if ((EXP & 8) != 0) {
+        if (T3 && !ABSGRAD) {
             // three terms: rows Q 0..3, W 4..7 (words hi | mid), Q 8..11, W 12..15 (words lo | 0); groups 2, 3 are added to 0, 1 in mm_finish
             mm.acc_off = g == 0 ? (j < 6 ? j : -1) : g == 1 ? (j >= 6 && j < 12 ? j : -1) : -1;
         } else {
-            // rows: Q 0..7, W 8..15  ->  groups 0, 1 hold Q of splats 4 g + r, groups 2, 3 hold W of splats 4 (g - 2) + r
-            const int col = g < 2 ? (j < 6 ? j : -1) : (j >= 6 && j < 12 ? j : -1);
-            mm.acc_off = col < 0 ? -1 : 4 * (g & 1) * AW + col;
+            // rows of one splat adjacent (mm_finish): this lane's column inside the sum row of ITS splat (ABSGRAD: splat g, the lo
+            // colour columns merged away; else splats 2 g and 2 g + 1, a row of AW floats apart)
+            mm.acc_off = j < (ABSGRAD ? 9 : 12) ? (ABSGRAD ? g : 2 * g) * AW + j : -1;
         }
     }
 
@@ -461,10 +543,17 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
             const RecRegs rec = load_rec(splats, id_cur);
             stage_splat(L.f, tid, rec, xc, yc);
             if (id_cur >= 0) {
-                L.geo[tid] = make_float4(rec.a.x - xc, rec.a.y - yc, rec.a.z, rec.a.w);
-                L.geo2[tid] = make_float2(rec.bb.x, rec.bb.y > 0.f ? 1.f / rec.bb.y : 0.f);
-                L.id[tid] = id_cur;
+                const float mx_ = rec.a.x - xc, my_ = rec.a.y - yc, io_ = rec.bb.y > 0.f ? 1.f / rec.bb.y : 0.f;
+                L.geo[tid] = make_float4(mx_, my_, rec.a.z, rec.a.w);
+                if constexpr (ABSGRAD)
+                    L.geo2[tid] = make_float4(rec.bb.x, io_, __builtin_fmaf(rec.a.z, mx_, rec.a.w * my_), __builtin_fmaf(rec.a.w, mx_, rec.bb.x * my_));
+                else
+                    L.geo2[tid] = make_float2(rec.bb.x, io_);
+                reinterpret_cast<int*>(&L.f.uni[tid])[3] = id_cur;       // (behind stage_splat's store of the record, same thread)
             }
+            // log2 alpha <= log2 o + 3e-4 (rasterize_mfma.h: alpha_of): below o = 0.998 the clamp at 0.999 can not be reached
+            const unsigned long long hb = wave_ballot(id_cur >= 0 && rec.bb.y >= 0.998f);
+            if ((lane & 31) == 0) L.hot[tid >> 5] = (unsigned)(hb >> (lane & 32)) != 0u ? 1u : 0u;
         }
         __syncthreads();
         if (be == bmax) RB_STAMP(4, wall_clock64());
@@ -476,66 +565,29 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
             for (int sb = g0 / SUB; sb < g0 / SUB + GRP / SUB; sb++) {
                 if (sb * SUB >= bsz || sb < k0 / SUB) continue;
                 float s[SUB];
-                eval_sub_batch(L.f, sb, lane, basis, s);
-                if (be - sb * SUB <= wmin)
-                    bwd_sub_batch_mm<ABSGRAD, true, EXP, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
+                const SubUni U = load_sub_uni<ABSGRAD, SH>(L, sb, lane);       // (in front of the MFMAs: their latency covers the reads)
+                if (ABSGRAD && !SH::PIPELINE) {
+                    // the alpha basis rebuilt here instead of held across the visits: ten registers that let hipcc keep ABSGRAD's
+                    // WIDE instance at 128 without spilling (plain: 305 -> 314 us, ABSGRAD 474 -> 471; only the latter takes it)
+                    int wv_ = wv, lane_ = lane;
+                    asm volatile("" : "+v"(wv_), "+v"(lane_));
+                    eval_sub_batch(L.f, sb, lane, make_basis(wv_, lane_), s);
+                } else {
+                    eval_sub_batch(L.f, sb, lane, basis, s);
+                }
+                // (the reads have landed behind the MFMAs; used here once, hipcc does not wait for them again in every visit's block)
+                asm volatile("" :: "v"(U.r), "v"(U.g), "v"(U.b));
+                if (ABSGRAD) asm volatile("" :: "v"(U.A), "v"(U.B), "v"(U.C), "v"(U.ax), "v"(U.ay));
+                if (be - sb * SUB <= wmin && has == ~0ull && !L.hot[sb])
+                    bwd_sub_batch_mm<ABSGRAD, true, T3, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
                 else
-                    bwd_sub_batch_mm<ABSGRAD, false, EXP, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, tail, T, bufdot, v_splats);
+                    bwd_sub_batch_mm<ABSGRAD, false, T3, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
             }
-            mm_drain<ABSGRAD, (EXP & 4) != 0, (EXP & 8) != 0 && !ABSGRAD, SH>(L, P, mm, wv, lane, v_splats);
-            if (EXP & 5) continue;          // 1: timing experiment, no group barriers, no flush; 4: the waves have flushed themselves
+            mm_drain<ABSGRAD, T3 && !ABSGRAD, SH>(L, P, mm, wv, lane);
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
             if (be == bmax && g0 == 0) RB_STAMP(5, wall_clock64());
-            // flush: lane -> (slot = lane >> 4, column = lane & 15), 16 slots per round over the block.  A wave's 4 slots lie in
-            // one chunk, so "which quadrants have sums for it" is wave-uniform.  The gradients of (x, y, conic A, B, C, opacity)
-            // follow from the moments about the tile centre:
-            //   sum q dx = mx M - Mu, sum q dx^2 = mx^2 M - 2 mx Mu + Muu, ...   (dx = mx - u, dy = my - v)
-            const unsigned long long m0 = L.gmask[0], m1 = L.gmask[1], m2 = L.gmask[2], m3 = L.gmask[3];
-            if ((m0 | m1 | m2 | m3) != 0ull) {
-#pragma unroll 1
-                for (int rd = 0; rd < GRP / 16; rd++) {
-                    // this wave's four slots of the round: skip it if no quadrant has anything for them
-                    const int sg0 = rd * 16 + 4 * wv;
-                    if ((((m0 | m1 | m2 | m3) >> sg0) & 15ull) == 0ull) continue;
-                    const int sg = sg0 + (lane >> 4);
-                    const int comp = lane & 15;
-                    const int cc = comp < AW ? comp : 0;
-                    float sum = 0.f;
-                    if ((m0 >> sg) & 1ull) sum += L.accw[0][sg][cc];
-                    if ((m1 >> sg) & 1ull) sum += L.accw[1][sg][cc];
-                    if ((m2 >> sg) & 1ull) sum += L.accw[2][sg][cc];
-                    if ((m3 >> sg) & 1ull) sum += L.accw[3][sg][cc];
-                    const int slot = g0 + sg;
-                    const unsigned long long nz = wave_ballot(slot < bsz && comp < AW && sum != 0.f);
-                    const bool touched = ((nz >> (lane & 48)) & 0xFFFFull) != 0ull;
-                    // the other columns of this slot, from the 16 lanes that hold them
-                    const int rb = lane & 48;
-                    const float M = __shfl(sum, rb + AC_Q, 64), Mu = __shfl(sum, rb + AC_QU, 64), Mv = __shfl(sum, rb + AC_QV, 64);
-                    // second operand by output component: x, y none; conic A, B, C their second moments; r, g, b the lo sums
-                    const int xsrc = comp == GR_CA ? AC_QUU : comp == GR_CB ? AC_QUV : comp == GR_CC ? AC_QVV
-                                     : (!(ABSGRAD && AbsCols<SH>::MERGE) && comp >= GR_R && comp <= GR_B) ? comp + 3 : comp == GR_ABSX ? AbsCols<SH>::ABSX : comp == GR_ABSY ? AbsCols<SH>::ABSY : 0;
-                    const float X = __shfl(sum, rb + xsrc, 64);
-                    if (slot < bsz && touched && comp < (ABSGRAD ? GR_DEPTH : GR_ABSX)) {
-                        const float4 ge = L.geo[slot];
-                        const float2 g2 = L.geo2[slot];
-                        const float mx = ge.x, my = ge.y;
-                        const float sdx = mx * M - Mu, sdy = my * M - Mv;                 // sum q dx, sum q dy
-                        float val;
-                        switch (comp) {
-                            case GR_X: val = -(ge.z * sdx + ge.w * sdy); break;
-                            case GR_Y: val = -(ge.w * sdx + g2.x * sdy); break;
-                            case GR_CA: val = -0.5f * (mx * (mx * M - 2.f * Mu) + X); break;
-                            case GR_CB: val = -(mx * (my * M - Mv) - my * Mu + X); break;
-                            case GR_CC: val = -0.5f * (my * (my * M - 2.f * Mv) + X); break;
-                            case GR_OPA: val = M * g2.y; break;
-                            case GR_R: case GR_G: case GR_B: val = (ABSGRAD && AbsCols<SH>::MERGE) ? sum : sum + X; break;
-                            default: val = X; break;          // |x|, |y|
-                        }
-                        atomicAdd(&v_splats[(size_t)L.id[slot] * GRAD_STRIDE + comp], val);
-                    }
-                }
-            }
+            flush_group_lane_per_slot<ABSGRAD, SH>(L, wv, lane, g0, bsz, v_splats);
             __syncthreads();
         }
     }
@@ -555,7 +607,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 constexpr int SEG_WORKERS = 512, SEG_WORKERS_MANY = 1024;
 constexpr size_t SEG_MANY_ITEMS = 4096;      // workspace sized for more than a million intersections
 
-template <bool HAS_BG, bool ABSGRAD, int EXP, typename SH>
+template <bool HAS_BG, bool ABSGRAD, bool T3, typename SH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
@@ -588,8 +640,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
             if (item >= n_items) return;
             __syncthreads();                             // the walk before may still be reading L
         }
-        bwd_walk<HAS_BG, ABSGRAD, EXP, SH>(L, t, item, seg, render, W, H, tw, th, splats, tile_offsets, flatten_ids, n_isect_ptr,
-                                           n_tiles_total, backgrounds, alphas, last_ids, v_render, v_alphas, v_splats);
+        bwd_walk<HAS_BG, ABSGRAD, T3, SH>(L, t, item, seg, render, W, H, tw, th, splats, tile_offsets, flatten_ids, n_isect_ptr,
+                                          n_tiles_total, backgrounds, alphas, last_ids, v_render, v_alphas, v_splats);
         if (item < 0) return;
         item += n_workers;
     }
@@ -607,9 +659,8 @@ static long long bwd_wide_min() {
 }
 
 // experiment: 0 = the product kernel, the only one the product library holds.  Experiments build (libmi3dgs_exp.so):
-// 4 = three-term transport of the pixel sums (correct), 14 = the wave-flush variant (correct); 11..13 = timing experiments with
-// WRONG results, kept for the measurements quoted in docs/FINDINGS_r01_r02.md (bit 0 no group barriers / flush, bit 1 no colour
-// reads; only without background and absgrad); 21 / 22 = force the DEEP / WIDE shape
+// 4 = three-term transport of the pixel sums (24 significant bits; the precision A/B of profiles/r03_bwd_terms_ab.txt and
+// profiles/r04_precision_ab.txt), 21 / 22 = force the DEEP / WIDE shape.
 int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
@@ -627,8 +678,8 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     const bool many_items = seg.ckpt && (size_t)seg.cap > (size_t)n_tiles + 16 + SEG_MANY_ITEMS;
     const int n_workers = seg.ckpt ? (many_items ? SEG_WORKERS_MANY : SEG_WORKERS) : 0;
     const int grid = raster_grid(n_tiles, tile_width) + n_workers;
-#define LAUNCH_MM(BG, AG, E, SH)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, E, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
+#define LAUNCH_MM(BG, AG, T3, SH)                                                                                                 \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, T3, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, raster_bands(), n_workers, seg, render)
     // with the segment workspace no walk is longer than 512 entries and a launch is many short blocks whose fixed cost (three
@@ -638,31 +689,18 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
 #ifdef MI3DGS_EXPERIMENTS
     if (experiment == 21 || experiment == 22) { wide = experiment == 22; experiment = 0; }
     if (experiment == 4 && !absgrad) {           // three-term transport of the pixel sums (correct results, 24 significant bits)
-        if (backgrounds) LAUNCH_MM(true, false, 8, ShapeDeep); else LAUNCH_MM(false, false, 8, ShapeDeep);
-        MI_LAUNCH_CHECK();
-        return 0;
-    }
-    if (experiment == 14) {           // wave-flush variant (correct results)
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 4, ShapeDeep); else LAUNCH_MM(true, false, 4, ShapeDeep); }
-        else { if (absgrad) LAUNCH_MM(false, true, 4, ShapeDeep); else LAUNCH_MM(false, false, 4, ShapeDeep); }
-        MI_LAUNCH_CHECK();
-        return 0;
-    }
-    if (experiment >= 11 && experiment <= 13 && !backgrounds && !absgrad) {
-        if (experiment == 11) LAUNCH_MM(false, false, 1, ShapeDeep);
-        else if (experiment == 12) LAUNCH_MM(false, false, 2, ShapeDeep);
-        else LAUNCH_MM(false, false, 3, ShapeDeep);
+        if (backgrounds) LAUNCH_MM(true, false, true, ShapeDeep); else LAUNCH_MM(false, false, true, ShapeDeep);
         MI_LAUNCH_CHECK();
         return 0;
     }
 #endif
     MI_REQUIRE(experiment == 0, "rasterize_bwd: unknown variant");
     if (wide) {
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0, ShapeWide); else LAUNCH_MM(true, false, 0, ShapeWide); }
-        else { if (absgrad) LAUNCH_MM(false, true, 0, ShapeWide); else LAUNCH_MM(false, false, 0, ShapeWide); }
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, false, ShapeWide); else LAUNCH_MM(true, false, false, ShapeWide); }
+        else { if (absgrad) LAUNCH_MM(false, true, false, ShapeWide); else LAUNCH_MM(false, false, false, ShapeWide); }
     } else {
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, 0, ShapeDeep); else LAUNCH_MM(true, false, 0, ShapeDeep); }
-        else { if (absgrad) LAUNCH_MM(false, true, 0, ShapeDeep); else LAUNCH_MM(false, false, 0, ShapeDeep); }
+        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, false, ShapeDeep); else LAUNCH_MM(true, false, false, ShapeDeep); }
+        else { if (absgrad) LAUNCH_MM(false, true, false, ShapeDeep); else LAUNCH_MM(false, false, false, ShapeDeep); }
     }
 #undef LAUNCH_MM
     MI_LAUNCH_CHECK();

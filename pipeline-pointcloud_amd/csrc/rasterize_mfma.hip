@@ -98,7 +98,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
             for (int i = 0; i < SUB; i++) {
                 if ((i & 7) == 0 && i > 0 && live == 0ull) break;
                 const Rgb col = col_next;
-                col_next = lds_rgb(uni, i + 1);                 // one visit ahead: its latency hides behind this visit
+                // one visit ahead: its latency hides behind this visit.  (Round 4 tried the backward's scheme here -- one read per
+                // sub-batch, v_readlane in the visits that composite: S2 137.5 -> 141.6 us, S1 56.0 -> 56.8, wolf 87.1 -> 81.6;
+                // the forward has no stores for the read to queue behind, and it stays as it is.)
+                col_next = lds_rgb(uni, i + 1);
                 const unsigned long long hit = mask_ge(s[i], LOG2_ALPHA_THRESHOLD) & live;
                 if (hit == 0ull) continue;
                 const float alpha = alpha_of(s[i]);
@@ -712,8 +715,8 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           void* seg_ws, size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
     // mode 1: the contraction on the matrix pipe (rasterize_bwd_mm.hip), the product path and the only one of the product
-    // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 and 11..14 = variants of the product
-    // kernel (rasterize_bwd_mm.hip: 4 three-term sums, 14 wave flush, 11..13 timing experiments with wrong results)
+    // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 / 21 / 22 = variants of the product
+    // kernel (rasterize_bwd_mm.hip: three-term sums, forced shapes)
 #ifdef MI3DGS_EXPERIMENTS
     if (mode == 3) {
 #define LAUNCH_BWD(BG, AG)                                                                                                 \

@@ -286,6 +286,7 @@ def export_frame_splats(tr, ds) -> Dict[str, torch.Tensor]:
     back to the COLMAP world; the reference's fixed corrections (rotate_splat x:270,y:180,z:0 main.py:1481-1500,
     mirror x :1510-1523, x:180,y:180 :1556-1592) and its metric-scale stages start from that frame
     (dataset.py: frame="nerfstudio" is z-up, centred on the cameras, cameras within the unit cube)."""
+    tr._settle()            # (a step that raised half-way may have left the side stream's Adam unordered against this read)
     return tr.model.splats_state_dict()
 
 

@@ -112,7 +112,8 @@ class TrainConfig:
 class GaussianModel:
     """Parameter + Adam-moment store with spare capacity and two banks (densify ping-pong)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None, flat: bool = False, align: int = 1):
+    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None, flat: bool = False, align: int = 1,
+                 slab_skew: int = 0):
         """flat: parameters, both moments and the gradients each live in ONE allocation, group after group
         ([means | quats | scales | opacities | sh0 | shN], each [capacity, width]); the sharded optimiser
         reduce-scatters / all-gathers those buffers whole (parallel.py).  align: capacity is rounded up to it."""
@@ -128,7 +129,27 @@ class GaussianModel:
         cap = self.capacity
         self.flat: Optional[Dict] = None
         self.banks = []
-        if flat:
+        if slab_skew:
+            # (placement experiment, profiles/r04_pbwd_slab.txt) parameters and both moments of BOTH banks from ONE allocation, every
+            # array's base moved on by a distinct multiple of `slab_skew` bytes, so that where the ~20 arrays the fused backward +
+            # Adam streams at once sit relative to one another is decided here and not by what the allocator had lying around
+            P = (1 << 20) // 4                                  # every base = a multiple of 1 MiB + i * slab_skew bytes
+            tot = 2 * 3 * sum(WIDTHS) * cap + (2 * 3 * len(WIDTHS) + 1) * 2 * P
+            slab = torch.zeros(tot, dtype=torch.float32, device=dev)
+            base0 = (-(slab.data_ptr() // 4)) % P               # floats to the first 1 MiB boundary of the ADDRESS
+            self._slab, off, i = slab, base0, 0
+            for b in range(2):
+                bank = {}
+                for g, w in zip(GROUPS, WIDTHS):
+                    bank[g] = {}
+                    for k in ("p", "m", "v"):
+                        off = (off - base0 + P - 1) // P * P + base0 + (i * (slab_skew // 4)) % P
+                        bank[g][k] = slab[off: off + cap * w].view(cap, w)
+                        off += cap * w
+                        i += 1
+                self.banks.append(bank)
+            self.grads = {g: torch.zeros(cap, w, dtype=torch.float32, device=dev) for g, w in zip(GROUPS, WIDTHS)}
+        elif flat:
             tot = sum(WIDTHS) * cap
             self.flat = {k: [torch.zeros(tot, dtype=torch.float32, device=dev) for _ in range(2)] for k in ("p", "m", "v")}
             self.flat["g"] = torch.zeros(tot, dtype=torch.float32, device=dev)
@@ -225,6 +246,7 @@ class Trainer:
         self.dev_gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed + 1)   # per-step draws stay on the device
         self._bg_table: Optional[torch.Tensor] = None
         self._side_stream = None
+        self._step_open = False                    # True between a step's first launch and its last: an exception leaves it set
         self._overlap_on, self._overlap_checked_at, self.refine_count = None, -1, 0
         self.last: Dict = {}
         self.last_refine: Dict = {}
@@ -238,6 +260,8 @@ class Trainer:
         # "placement": 18 separate arrays 588-589 us, flat 548-575 us on the same box, profiles/r02_placement_ab.txt,
         # measured with the round-2 switch MI3DGS_FLAT_MODEL).  It is also what the sharded optimiser exchanges.
         import os
+        if os.environ.get("MI3DGS_SLAB_SKEW"):          # (placement experiment: tools/pbwd_placement.py --slab-skew)
+            return dict(slab_skew=int(os.environ["MI3DGS_SLAB_SKEW"]))
         return {} if os.environ.get("MI3DGS_SEPARATE_ARRAYS") else dict(flat=True)
 
     def _n(self) -> int:
@@ -328,16 +352,33 @@ class Trainer:
     @torch.no_grad()
     def render(self, viewmat: torch.Tensor, K: torch.Tensor, sh_degree: Optional[int] = None, background=None):
         """Render one view at full resolution: [1,H,W,3], [1,H,W,1].  (Outputs alias internal buffers.)"""
+        self._settle()
         self.set_resolution(1)
         sd = self.cfg.sh_degree if sh_degree is None else sh_degree
         # (an arbitrary camera: the auto-sized capacity was measured on the training views only, so count exactly here)
         _, _, _, render, alphas, _ = self._forward(viewmat.view(1, 4, 4), K.view(1, 3, 3), sd, background, exact_isect=True)
         return render, alphas
 
+    def _settle(self) -> None:
+        """A step that raised between its launches (a Mi3dgsError, a refused fast path) leaves three invariants open that the next
+        consumer relies on: v_splats clear except for what the projection backward clears itself, the segment
+        workspace's counters reset by the backward that follows every forward, and the side stream's Adam ordered before the main
+        stream's next reader.  Called at the head of step(), render(), refine() and by the checkpoint / export paths via
+        `splats_state_dict` of the CLI; a no-op after a step that completed."""
+        if not self._step_open:
+            return
+        torch.cuda.synchronize(self.device)       # both streams: whatever the aborted step launched has finished
+        self.v_splats.zero_()
+        ws = self.raster_out.get("seg_ws")
+        if ws is not None:
+            ops._lib.call("mi3dgs_raster_seg_workspace_init", ops._p(ws), ws.numel(), ops._stream(self.device))
+        self._step_open = False
+
     # -- one training iteration ------------------------------------------------------
     @torch.no_grad()
     def step(self, view_index: int, want_loss: bool = False):
         c, m = self.cfg, self.model
+        self._settle()
         n = self._n()
         self.set_resolution(self.downscale_now())
         if c.auto_isect_capacity and c.max_isect is None and self._auto_cap is None:
@@ -361,6 +402,7 @@ class Trainer:
         split = (fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd") and not sreg
                  and not any(regs) and self._overlap_pays())
         hooks = None
+        self._step_open = True
         if split:
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
@@ -411,6 +453,7 @@ class Trainer:
                 ops.scale_reg(m.p("scales"), c.scale_reg_weight, c.max_gauss_ratio, v_scales=m.grad("scales"))
             self._grad_hooks()
             self._optimizer_step(n)
+        self._step_open = False
         if c.densify:
             self._strategy_post_step()
         self.last = dict(binning=binning, sums=sums)
@@ -522,6 +565,7 @@ class Trainer:
     def refine(self, do_grow: bool = True) -> Dict[str, int]:
         """One densify+prune pass; returns counts.  One host sync (the new Gaussian count)."""
         c, m = self.cfg, self.model
+        self._settle()
         self.check_async_errors()                    # the host waits here anyway: did every chained kernel resolve?
         self.v_splats.zero_()                        # (belt and braces: the steps keep it clear themselves, see step())
         self.refine_count += 1

@@ -443,7 +443,8 @@ def test_s2_training_step_properties_and_fused_adam(dev):
     n = g.params["means"].shape[0]
     vm, ks = g.viewmats[:2].contiguous(), g.Ks[:2].contiguous()
     tgt = torch.rand(2, sc.height, sc.width, 3, device=dev)
-    cfgs = [trainer.TrainConfig(capacity=n, refine_start_iter=10 ** 9, max_isect=40_000_000, fuse_adam=f) for f in (True, False)]
+    cfgs = [trainer.TrainConfig(capacity=n, refine_start_iter=10 ** 9, max_isect=40_000_000, fuse_adam=f, refine_scale2d_stop_iter=4000)
+            for f in (True, False)]            # (step 3001 < 4000: the screen-radius statistic is written too)
     trs = [trainer.Trainer(g.params, vm, ks, tgt, sc.width, sc.height, c) for c in cfgs]
     for tr in trs:
         tr.step_count = 3001

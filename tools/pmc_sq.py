@@ -3,7 +3,12 @@ import csv, re, sys
 from collections import defaultdict
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("mfma_raster::", "").replace("void ", "")
-    return re.sub(r"_kernel$", "", re.sub(r"[<(].*", "", n))
+    base = re.sub(r"_kernel$", "", re.sub(r"[<(].*", "", n))
+    if base in ("rasterize_bwd_mm", "project_bwd1"):          # the instantiations are different kernels: <HAS_BG, ABSGRAD, EXP, Shape> / <FUSE>
+        m = re.search(r"<([^>]*)>", n)
+        if m:
+            base += "<" + m.group(1).replace("mfma_raster::", "").replace(" ", "") + ">"
+    return base
 files = [a for a in sys.argv[1:] if not a.startswith("--")]
 want = None
 for a in sys.argv[1:]:
