@@ -112,8 +112,7 @@ class TrainConfig:
 class GaussianModel:
     """Parameter + Adam-moment store with spare capacity and two banks (densify ping-pong)."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None, flat: bool = False, align: int = 1,
-                 slab_skew: int = 0):
+    def __init__(self, params: Dict[str, torch.Tensor], capacity: Optional[int] = None, flat: bool = False, align: int = 1):
         """flat: parameters, both moments and the gradients each live in ONE allocation, group after group
         ([means | quats | scales | opacities | sh0 | shN], each [capacity, width]); the sharded optimiser
         reduce-scatters / all-gathers those buffers whole (parallel.py).  align: capacity is rounded up to it."""
@@ -129,27 +128,7 @@ class GaussianModel:
         cap = self.capacity
         self.flat: Optional[Dict] = None
         self.banks = []
-        if slab_skew:
-            # (placement experiment, profiles/r04_pbwd_slab.txt) parameters and both moments of BOTH banks from ONE allocation, every
-            # array's base moved on by a distinct multiple of `slab_skew` bytes, so that where the ~20 arrays the fused backward +
-            # Adam streams at once sit relative to one another is decided here and not by what the allocator had lying around
-            P = (1 << 20) // 4                                  # every base = a multiple of 1 MiB + i * slab_skew bytes
-            tot = 2 * 3 * sum(WIDTHS) * cap + (2 * 3 * len(WIDTHS) + 1) * 2 * P
-            slab = torch.zeros(tot, dtype=torch.float32, device=dev)
-            base0 = (-(slab.data_ptr() // 4)) % P               # floats to the first 1 MiB boundary of the ADDRESS
-            self._slab, off, i = slab, base0, 0
-            for b in range(2):
-                bank = {}
-                for g, w in zip(GROUPS, WIDTHS):
-                    bank[g] = {}
-                    for k in ("p", "m", "v"):
-                        off = (off - base0 + P - 1) // P * P + base0 + (i * (slab_skew // 4)) % P
-                        bank[g][k] = slab[off: off + cap * w].view(cap, w)
-                        off += cap * w
-                        i += 1
-                self.banks.append(bank)
-            self.grads = {g: torch.zeros(cap, w, dtype=torch.float32, device=dev) for g, w in zip(GROUPS, WIDTHS)}
-        elif flat:
+        if flat:
             tot = sum(WIDTHS) * cap
             self.flat = {k: [torch.zeros(tot, dtype=torch.float32, device=dev) for _ in range(2)] for k in ("p", "m", "v")}
             self.flat["g"] = torch.zeros(tot, dtype=torch.float32, device=dev)
@@ -260,8 +239,6 @@ class Trainer:
         # "placement": 18 separate arrays 588-589 us, flat 548-575 us on the same box, profiles/r02_placement_ab.txt,
         # measured with the round-2 switch MI3DGS_FLAT_MODEL).  It is also what the sharded optimiser exchanges.
         import os
-        if os.environ.get("MI3DGS_SLAB_SKEW"):          # (placement experiment: tools/pbwd_placement.py --slab-skew)
-            return dict(slab_skew=int(os.environ["MI3DGS_SLAB_SKEW"]))
         return {} if os.environ.get("MI3DGS_SEPARATE_ARRAYS") else dict(flat=True)
 
     def _n(self) -> int:

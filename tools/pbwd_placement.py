@@ -18,10 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--history", default="bench", choices=["bench", "first", "churn"])
-    ap.add_argument("--slab-skew", type=int, default=0, help="bytes: the model from ONE allocation, array i at a 1 MiB boundary + i x this (GaussianModel slab_skew)")
     a = ap.parse_args()
-    if a.slab_skew:
-        os.environ["MI3DGS_SLAB_SKEW"] = str(a.slab_skew)
     import bench
     from mi3dgs import _lib, scenes, trainer
     dev = torch.device("cuda:0")
@@ -65,7 +62,7 @@ def main():
     torch.cuda.synchronize()
     _lib.STAGE_HOOK = None
     t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev[2:])
-    print(json.dumps(dict(history=a.history, slab_skew=a.slab_skew, project_bwd_adam_us=round(t[len(t) // 2], 1), minmax=[round(t[0], 1), round(t[-1], 1)],
+    print(json.dumps(dict(history=a.history, project_bwd_adam_us=round(t[len(t) // 2], 1), minmax=[round(t[0], 1), round(t[-1], 1)],
                           errors=_lib.async_errors())), flush=True)
 
 
