@@ -125,7 +125,7 @@ def splatfacto_config(model: str, max_steps: int, scale_reg: bool, n_train: int,
         # split_screen_size / cull_screen_size / stop_screen_size_at
         grow_scale2d=0.05, prune_scale2d=0.15, refine_scale2d_stop_iter=4000,
         pause_refine_after_reset=n_train + 100, absgrad=True, use_scale_regularization=scale_reg,
-        random_background=True, capacity=capacity, auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True, overlap_culled_adam="after_binning",
+        random_background=True, capacity=capacity, auto_isect_capacity=True, spatial_sort_init=True, overlap_culled_adam="after_binning",
         num_downscales=2, resolution_schedule=3000)          # splatfacto: 1/4 -> 1/2 -> full, every 3000 steps
 
 
@@ -134,7 +134,7 @@ def simple_trainer_config(a: Dict, capacity: int):
     cfg = TrainConfig(max_steps=a["max_steps"], capacity=capacity, antialiased=a["antialiased"],
                       random_background=a["random_bkgd"], absgrad=a["absgrad"],
                       grow_grad2d=0.0008 if a["absgrad"] else 0.0002, scene_scale=1.1,
-                      auto_isect_capacity=os.environ.get("MI3DGS_AUTO_ISECT", "1") != "0", spatial_sort_init=True, overlap_culled_adam="after_binning")
+                      auto_isect_capacity=True, spatial_sort_init=True, overlap_culled_adam="after_binning")
     f = a["steps_scaler"]
     if f != 1.0:        # gsplat Config.adjust_steps
         import dataclasses
@@ -183,9 +183,6 @@ def run_training(data_dir: str, downscale: int, cfg, *, ctx=None, log_every: int
     ds = ds_mod.load_colmap_dataset(data_dir, downscale, frame=frame)
     if callable(cfg):
         cfg = cfg(ds)
-    if os.environ.get("MI3DGS_FWD_SEGMENTS") == "1":          # A/B of the forward in segments
-        import dataclasses
-        cfg = dataclasses.replace(cfg, raster_fwd_segments=True)
     n_pts = ds.points.shape[0]
     say(f"dataset: {len(ds.train_idx)} train / {len(ds.eval_idx)} eval images {ds.width}x{ds.height}, {n_pts} SfM points")
     params = ds_mod.init_gaussians(ds.points.to(dev), ds.points_rgb, init_opacity=init_opacity, init_scale=init_scale)

@@ -235,11 +235,9 @@ class Trainer:
     def _model_layout(self) -> Dict:
         """Keyword arguments for GaussianModel (the sharded data-parallel trainer asks for flat buffers)."""
         # One allocation per kind (parameters, exp_avg, exp_avg_sq, gradients) instead of eighteen: the fused backward +
-        # Adam kernel streams all of them at once and its speed depends on where their pages landed (DESIGN.md,
-        # "placement": 18 separate arrays 588-589 us, flat 548-575 us on the same box, profiles/r02_placement_ab.txt,
-        # measured with the round-2 switch MI3DGS_FLAT_MODEL).  It is also what the sharded optimiser exchanges.
-        import os
-        return {} if os.environ.get("MI3DGS_SEPARATE_ARRAYS") else dict(flat=True)
+        # Adam kernel streams all of them at once (18 separate arrays 588-589 us, flat 548-575 us on the same box,
+        # profiles/r02_placement_ab.txt).  It is also what the sharded optimiser exchanges.
+        return dict(flat=True)
 
     def _n(self) -> int:
         return self.model.n

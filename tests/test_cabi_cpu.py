@@ -76,6 +76,22 @@ def test_product_library_holds_no_experiment_switch(built):
                 assert k not in txt, (f, k)
 
 
+def test_python_side_reads_only_the_documented_environment_switches():
+    """VERDICT r3 #10 (iii): the host side's own switches are listed in INTEGRATION.md section C, and nothing else is read."""
+    pkg = os.path.join(ROOT, "pipeline-pointcloud_amd", "mi3dgs")
+    read = set()
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            txt = open(os.path.join(pkg, f)).read()
+            read |= set(re.findall(r"environ(?:\.get\(|\[)\s*[\"'](MI3DGS_[A-Z0-9_]+)", txt))
+    allowed = {"MI3DGS_LIB", "MI3DGS_SYNC_EACH_CALL", "MI3DGS_PROFILE_STEPS", "MI3DGS_EVAL_DETAIL", "MI3DGS_LIST_STATS", "MI3DGS_SINGLE_GPU",
+               "MI3DGS_FAKE_DEVICE_COUNT", "MI3DGS_MCMC_LOG", "MI3DGS_NAN_CHECK"}
+    assert read == allowed, read ^ allowed
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for k in allowed:
+        assert k in doc, k
+
+
 def test_workspace_queries_are_host_only(built):
     lib = built.lib()
     a = lib.mi3dgs_bin_workspace_bytes(1, 1000, 0)

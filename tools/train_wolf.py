@@ -36,10 +36,20 @@ def main():
     ap.add_argument("--backdrop", type=int, default=12_000,
                     help="Gaussians of an opaque, smoothly coloured shell around the wolf (radius 9 x its extent): every pixel shows "
                          "content, like a photograph in a room (0 = none: constant background 0.15, the round-2 dataset)")
+    ap.add_argument("--raster-mode", type=int, default=1,
+                    help="precision A/B (profiles/r04_precision_ab.txt): 1 = the product backward (pixel sums as two bf16 terms); from the "
+                         "EXPERIMENTS library: 3 = all-f32 cross-lane reduce-scatter backward, 4 = three bf16 terms (no absgrad)")
     a, extra = ap.parse_known_args()         # extra: passed on to ns-train
+    if a.raster_mode != 1:
+        os.environ["MI3DGS_LIB"] = os.path.join(ROOT, "pipeline-pointcloud_amd", "mi3dgs", "libmi3dgs_exp.so")
     from PIL import Image
     from helpers import load_wolf
     from mi3dgs import cli, io_colmap, io_ply, scenes, trainer
+    if a.raster_mode != 1:
+        from mi3dgs import _lib, ops
+        assert _lib.lib().mi3dgs_debug_set_raster_mode(a.raster_mode) == 0, _lib.lib().mi3dgs_last_error()
+        if a.raster_mode == 3:               # that backward walks whole lists and knows nothing of the forward's checkpoints
+            ops.raster_seg_workspace = lambda *args, **kw: None
     dev = torch.device("cuda:0")
     root = tempfile.mkdtemp(prefix="mi3dgs_wolf_")
     os.makedirs(os.path.join(root, "images"))
