@@ -18,6 +18,9 @@ def short(name):
     n = n.replace("project_bwd1_kernel<true, true>", "project_bwd_adam_probe").replace("project_bwd1_kernel<true, false>", "project_bwd_adam")
     n = n.replace("project_bwd1_kernel<false, false>", "project_bwd")
     n = n.replace("project_bwd1_kernel<true>", "project_bwd_adam").replace("project_bwd1_kernel<false>", "project_bwd")
+    m = re.match(r"rasterize_bwd_mm_kernel<(\w+), (\w+),", n)
+    if m:       # <HAS_BG, ABSGRAD, ...>: the `ns-train splatfacto` preset (bench.py's default) runs the ABSGRAD instance
+        return "rasterize_bwd_mm" if m.group(2) == "true" else "rasterize_bwd_mm_plain"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"<.*", "", n)
     return n.replace("_kernel", "")
