@@ -45,7 +45,6 @@ typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-constexpr int TR_STRIDE = 68;
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
 constexpr int AW = 12;                    // floats per (wave, slot) sum row: 48 bytes, read by the flush as three float4
@@ -73,12 +72,15 @@ constexpr int ABS_COL_X = 9, ABS_COL_Y = 10;
 template <bool ABSGRAD, typename SH>
 struct StagedBwdMM {
     static constexpr int STG = SH::STG;
+    // words per transposition row.  (68 puts rows 11 and 12 of a ds_read_b128's 16-lane groups on one bank; 72 is conflict-free for
+    // that read and measured the same to 0.1 % on S2, S1 and wolf -- the reads are not what the kernel waits for -- so the smaller one stays.)
+    static constexpr int TRS = 68;
     StagedN<STG> f;           // (the Gaussian's index rides in the fourth word of its colour record, f.uni[slot].w)
     float4 geo[STG];          // mx, my (relative to the tile centre), A, B
     // C, 1 / o [, ax = A mx + B my, ay = B mx + C my: the constant terms of d sigma / d(mx, my) as forms in (u, v)]
     typename std::conditional<ABSGRAD, float4, float2>::type geo2[STG];
     alignas(16) float accw[4][GRP][AW];
-    alignas(16) unsigned tr[4][TR_ROWS][TR_STRIDE];      // per wave: rows = (splat of the chunk, value), columns = the wave's 64 pixels
+    alignas(16) unsigned tr[4][TR_ROWS][TRS];      // per wave: rows = (splat of the chunk, value), columns = the wave's 64 pixels
     unsigned hot[STG / SUB];            // per sub-batch: some splat's opacity is >= 0.998 (the alpha clamp at 0.999 can be active)
     unsigned long long gmask[4];        // per wave: slots of the current group whose visit was live (its sums are meaningful)
     int wave_max[4];
@@ -221,6 +223,7 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, co
     constexpr bool T3 = T3_ && !ABSGRAD;         // three-term transport (experiments build)
     constexpr int CH = (ABSGRAD || T3) ? 4 : 8;  // splats per chunk: CH x (2 or 4 values) = 16 rows
     constexpr int KINDS = 16 / CH;
+    constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD, SH>::TRS;
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     unsigned* trw = &L.tr[wv][0][lane];
     // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
@@ -494,6 +497,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
         // each lane worked the sixteen values out itself -- pixel coordinates, selects by column, conversions, sixteen times over:
         // ~640 VALU instructions, 7.1 us of a short block's 16.2 at four waves per SIMD; tools/raster_ab.py probe.)
         {
+            constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD, SH>::TRS;
             unsigned* const trw = &L.tr[wv][0][lane];
             const float bas[6] = {px.u, px.v, px.uu, px.uv, px.vv, 1.f};
 #pragma unroll
