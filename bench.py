@@ -572,8 +572,8 @@ def main():
                 # radii (8) and, for the visible ones, the splat and gradient records (128)
                 # (with the culled groups split off: only the Gaussians of groups with a visible member, every radius still read)
                 "project_bwd_adam": n_vgrp * (708 + 708) + n * 8 + n_vis * 128,
-                # (the every-tenth step with splatfacto's scale regulariser: one launch over every Gaussian)
-                "project_bwd_adam/scale_reg": n * (708 + 708) + n * 8 + n_vis * 128,
+                # (the every-tenth step with splatfacto's scale regulariser: the same launch, its own tag)
+                "project_bwd_adam/scale_reg": n_vgrp * (708 + 708) + n * 8 + n_vis * 128,
                 # the culled groups' Adam on the second stream: p, m, v read and written, every radius read
                 "adam_culled_groups": (n - n_vgrp) * (708 + 708) + n * 8,
             }

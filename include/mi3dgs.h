@@ -58,10 +58,12 @@ extern "C" {
  * beside the rasterisers' and the loss kernels' waves on a second stream): the same bits as mi3dgs_project_bwd_adam gives those
  * Gaussians.  params / exp_avg / exp_avg_sq: HOST arrays of 6 device pointers (group order of mi3dgs_project_bwd_adam, 16-byte
  * aligned; opacities may be NULL in all three); radii[N][2]: this step's mi3dgs_project_fwd output, one camera.  Follow it with
- * mi3dgs_project_bwd_adam(..., flags | MI3DGS_FLAG_ONLY_VISIBLE_GROUPS, ...) with no scale regulariser in that step. */
+ * mi3dgs_project_bwd_adam(..., flags | MI3DGS_FLAG_ONLY_VISIBLE_GROUPS, ...) with the SAME scale_reg_weight / _max_ratio: in a step
+ * that applies splatfacto's scale regulariser (reference main.py:1288) that is the one gradient a culled Gaussian has, and this
+ * kernel forms it for the scales group (weight 0 = no regulariser in this step). */
 int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                               const int32_t* radii, const float* lrs, int step, float beta1, float beta2, float eps,
-                              void* stream);
+                              float scale_reg_weight, float scale_reg_max_ratio, void* stream);
 
 /* colour modes of project_fwd / project_bwd */
 #define MI3DGS_COLOR_SH 0          /* sh0[N,1,3] + shN[N,15,3], degree `sh_degree` */
@@ -72,13 +74,13 @@ int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg
  * results (tests/test_cabi_cpu.py checks that the binary holds no other MI3DGS_ name):
  *   MI3DGS_OS_SMALL_KEYS      sorts up to this many keys use 2 048-key onesweep tiles (default 512 K)
  *   MI3DGS_OS_MAX_KEYS        sorts above this many keys use the classic radix passes (default 4 M)
- *   MI3DGS_EMIT_SMALL_SPLATS  up to this many Gaussians the tile emit gives a wave 16 splats instead of 64 (default 128 K)
+ *   MI3DGS_EMIT_SMALL_SPLATS  up to this many Gaussians the tile emit gives a wave 16 splats instead of 64 (default 256 K)
  *   MI3DGS_KEYS16=0           never sort 16-bit tile keys
  *   MI3DGS_BWD_WIDE_MIN       from this many Gaussians on, rasterize_bwd runs its four-waves-per-SIMD shape (default 200 000)
  * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
  * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);
-int mi3dgs_abi_version(void);      /* 6 */
+int mi3dgs_abi_version(void);      /* 7 */
 int mi3dgs_splat_stride(void);
 int mi3dgs_grad_stride(void);
 

@@ -16,7 +16,7 @@ int mi_set_error_msg(const char* msg) {
 }
 
 extern "C" const char* mi3dgs_last_error(void) { return g_err; }
-extern "C" int mi3dgs_abi_version(void) { return 6; }
+extern "C" int mi3dgs_abi_version(void) { return 7; }
 extern "C" int mi3dgs_splat_stride(void) { return SPLAT_STRIDE; }
 extern "C" int mi3dgs_grad_stride(void) { return GRAD_STRIDE; }
 

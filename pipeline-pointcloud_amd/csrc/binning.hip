@@ -1437,9 +1437,10 @@ struct WaveEmitLds {
 };
 
 // SPW = splats per wave: 64, or 16 for small scenes (a wave's items are walked 64 at a time, serially: at 20 k big Gaussians
-// and 1080p a 64-splat wave has thousands of tile rows and the whole launch is 313 waves).
+// and 1080p a 64-splat wave has thousands of tile rows and the whole launch is 313 waves).  The switch-over is 256 K Gaussians:
+// 16 per wave measured 48 -> 32 us at 175 k real splats (wolf, 960 x 720, round 4) and 44 -> 79 us at 300 k small ones (S1, round 2).
 inline uint32_t we_small_splats() {
-    static const uint32_t v = [] { const char* e = getenv("MI3DGS_EMIT_SMALL_SPLATS"); return e ? (uint32_t)atol(e) : (128u << 10); }();
+    static const uint32_t v = [] { const char* e = getenv("MI3DGS_EMIT_SMALL_SPLATS"); return e ? (uint32_t)atol(e) : (256u << 10); }();
     return v;
 }
 inline int we_spw_for(uint32_t CN) {

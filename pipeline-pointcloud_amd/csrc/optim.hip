@@ -162,6 +162,7 @@ struct AdamGroupsArgs {
     float* p[6]; float* m[6]; float* v[6];
     float step_size[6];
     float b1, b2, eps, inv_bc2_sqrt, zero;
+    float sreg_weight, sreg_max_ratio;      // splatfacto's scale regulariser of this step (weight 0 = off): the one gradient a culled Gaussian has
 };
 
 __global__ __launch_bounds__(256) void adam_culled_groups_kernel(int N, const int32_t* __restrict__ radii, AdamGroupsArgs A) {
@@ -180,6 +181,33 @@ __global__ __launch_bounds__(256) void adam_culled_groups_kernel(int N, const in
 #pragma unroll 1
     for (int gi = 0; gi < 6; gi++) {
         if (A.p[gi] == nullptr) continue;                     // (no opacity array)
+        if (gi == 2 && A.sreg_weight > 0.f) {
+            // the scale regulariser's gradient, expression for expression as project_bwd1_kernel<true> forms it (csrc/project.hip),
+            // then the same mi_adam1: a lane per Gaussian for this group in such a step (every tenth of `ns-train splatfacto`)
+            if (lane < cnt) {
+                const long long o = 3 * (n0 + lane);
+                float sl[3] = {A.p[2][o], A.p[2][o + 1], A.p[2][o + 2]};
+                float mm[3] = {A.m[2][o], A.m[2][o + 1], A.m[2][o + 2]};
+                float vv[3] = {A.v[2][o], A.v[2][o + 1], A.v[2][o + 2]};
+                float vs[3] = {A.zero, A.zero, A.zero};
+                const float mx = fmaxf(sl[0], fmaxf(sl[1], sl[2])), mn = fminf(sl[0], fminf(sl[1], sl[2]));
+                const float ratio = __expf(mx - mn);
+                if (ratio > A.sreg_max_ratio) {
+                    const float gg = A.sreg_weight * ratio / (float)N;
+                    const int nmx = (sl[0] == mx) + (sl[1] == mx) + (sl[2] == mx);
+                    const int nmn = (sl[0] == mn) + (sl[1] == mn) + (sl[2] == mn);
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        vs[i] += (sl[i] == mx ? gg / (float)nmx : 0.f) - (sl[i] == mn ? gg / (float)nmn : 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    mi_adam1(sl[i], vs[i], mm[i], vv[i], A.step_size[2], A.b1, A.b2, A.inv_bc2_sqrt, A.eps);
+                    A.p[2][o + i] = sl[i]; A.m[2][o + i] = mm[i]; A.v[2][o + i] = vv[i];
+                }
+            }
+            continue;
+        }
         const int total = cnt * W_[gi];
         const long long base = n0 * W_[gi];                  // multiple of 4 floats: 64 Gaussians x any width
         float4* p4 = reinterpret_cast<float4*>(A.p[gi] + base);
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(256) void adam_culled_groups_kernel(int N, const in
 // null in all three); radii[N][2] of this step's mi3dgs_project_fwd (one camera).
 extern "C" int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                                          const int32_t* radii, const float* lrs, int step, float beta1, float beta2, float eps,
-                                         void* stream) {
+                                         float scale_reg_weight, float scale_reg_max_ratio, void* stream) {
     MI_REQUIRE(N >= 0 && params && exp_avg && exp_avg_sq && radii && lrs, "adam_culled_groups: null argument");
     MI_REQUIRE(step >= 1, "adam_culled_groups: step is 1-based");
     if (N == 0) return 0;
@@ -228,6 +256,7 @@ extern "C" int mi3dgs_adam_culled_groups(int N, float* const* params, float* con
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     for (int g = 0; g < 6; g++) A.step_size[g] = (float)(lrs[g] / bc1);
     A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); A.zero = 0.f;
+    A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
     MI_LAUNCH("adam_culled_groups", adam_culled_groups_kernel, dim3(mi_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, N, radii, A);
     MI_LAUNCH_CHECK();
     return 0;

@@ -1067,8 +1067,7 @@ static int project_bwd_adam_impl(int N, float* means, float* quats, float* scale
     A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     A.sreg_weight = scale_reg_weight; A.sreg_max_ratio = scale_reg_max_ratio;
     A.mcmc_opacity_reg = mcmc_opacity_reg; A.mcmc_scale_reg = mcmc_scale_reg;
-    // (profiler tag: the every-tenth step that carries splatfacto's scale regulariser updates EVERY Gaussian in this one launch,
-    //  also where the other steps leave the culled groups to mi3dgs_adam_culled_groups: a different number of bytes per launch)
+    // (profiler tag of its own for the every-tenth step that carries splatfacto's scale regulariser)
     MI_LAUNCH(scale_reg_weight > 0.f ? "project_bwd_adam/scale_reg" : "project_bwd_adam", (project_bwd1_kernel<true>), dim3(mi_div_up(N, 256)), dim3(256), 0,
               (hipStream_t)stream, N, means, quats, scales, opacities, shN, sh_degree, A, viewmats, Ks, width, height,
                   eps2d, flags, radii, splats, const_cast<float*>(v_splats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_grad2d,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MI3DGS_LIB") or os.path.join(_HERE, "libmi3dgs.so")
 # only by experiments_lib() -- the A/B tools under tools/ and the tests that use a rejected-but-correct variant as a yardstick
 EXP_LIB_PATH = os.path.join(_HERE, "libmi3dgs_exp.so")
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib: Optional[C.CDLL] = None
 _exp_lib: Optional[C.CDLL] = None
@@ -62,7 +62,7 @@ _SIGNATURES = {
     "mi3dgs_rasterize_bwd": (_i, [_i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _f, _ll, _f, _f, _sz, _f]),
     "mi3dgs_raster_seg_workspace_bytes": (_sz, [_i, _ll]),
     "mi3dgs_raster_seg_workspace_init": (_i, [_f, _sz, _f]),
-    "mi3dgs_adam_culled_groups": (_i, [_i, _f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _f]),
+    "mi3dgs_adam_culled_groups": (_i, [_i, _f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _fl, _fl, _f]),
     "mi3dgs_loss_fwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _f, _f]),
     "mi3dgs_loss_bwd": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _fl, _fl, _f, _f]),
     "mi3dgs_loss_fwd_u8": (_i, [_i, _i, _i, _f, _f, _fl, _f, _f, _f, _f, _f]),

@@ -154,13 +154,14 @@ def project_bwd_adam(params, exp_avg, exp_avg_sq, lrs, step, viewmat, K, width, 
               _p(sr), int(bool(stat_use_abs)), _stream(dev))
 
 
-def adam_culled_groups(params, exp_avg, exp_avg_sq, lrs, step, radii, *, n, beta1=0.9, beta2=0.999, eps=1e-15):
+def adam_culled_groups(params, exp_avg, exp_avg_sq, lrs, step, radii, *, n, beta1=0.9, beta2=0.999, eps=1e-15,
+                       scale_reg_weight=0.0, scale_reg_max_ratio=10.0):
     """Adam on the aligned 64-Gaussian groups none of whose members is visible in `radii` (zero gradient: a pure stream).
     The counterpart of project_bwd_adam(flags | FLAG_ONLY_VISIBLE_GROUPS)."""
     dev = params[0].device
     lr = (C.c_float * 6)(*[float(x) for x in lrs])
     _lib.call("mi3dgs_adam_culled_groups", int(n), _ptr_array(params), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), _p(radii), lr,
-              int(step), float(beta1), float(beta2), float(eps), _stream(dev))
+              int(step), float(beta1), float(beta2), float(eps), float(scale_reg_weight), float(scale_reg_max_ratio), _stream(dev))
 
 
 def bin_tiles(radii, splats, width, height, tile_size=16, *, max_isect: Optional[int] = None,

@@ -372,9 +372,10 @@ class Trainer:
         sreg = c.use_scale_regularization and self.step_count % c.scale_reg_every == 0
         # (a step that applies BOTH splatfacto's scale regulariser and a strategy's own regularisers takes the unfused launches)
         fused = c.fuse_adam and self._can_fuse_adam() and not (sreg and any(self._fused_regularisers()))
-        # (not in a step that applies the scale regulariser: that one gives culled Gaussians a gradient too)
+        # (a step that applies splatfacto's scale regulariser gives culled Gaussians a gradient too -- the only one they have:
+        #  mi3dgs_adam_culled_groups forms it for the scales group itself; MCMC's regularisers touch every group and keep one launch)
         regs = self._fused_regularisers() if fused else (0.0, 0.0)
-        split = (fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd") and not sreg
+        split = (fused and c.overlap_culled_adam in ("after_project", "after_binning", "after_raster_fwd")
                  and not any(regs) and self._overlap_pays())
         hooks = None
         self._step_open = True
@@ -392,7 +393,8 @@ class Trainer:
                     bank_ = m.banks[m.cur]
                     ops.adam_culled_groups([bank_[g]["p"] for g in GROUPS], [bank_[g]["m"] for g in GROUPS],
                                            [bank_[g]["v"] for g in GROUPS], self.lrs(), self.step_count + 1, radii_, n=n,
-                                           beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps)
+                                           beta1=c.adam_beta1, beta2=c.adam_beta2, eps=c.adam_eps,
+                                           scale_reg_weight=c.scale_reg_weight if sreg else 0.0, scale_reg_max_ratio=c.max_gauss_ratio)
                     self._ev_side.record(self._side_stream)
 
             hooks = {c.overlap_culled_adam: culled_groups}

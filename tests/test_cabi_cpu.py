@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
     h = ctypes.CDLL(built.LIB_PATH)
     for name in _declared():
         assert hasattr(h, name)
-    assert built.lib().mi3dgs_abi_version() == 6
+    assert built.lib().mi3dgs_abi_version() == 7
     assert built.lib().mi3dgs_splat_stride() == 16 and built.lib().mi3dgs_grad_stride() == 16
 
 

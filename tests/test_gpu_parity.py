@@ -663,8 +663,10 @@ def test_culled_groups_adam_on_a_second_stream_is_the_same_update(dev):
             assert rel_err(o[0][k], out[0][0][k]) < 2e-3 and rel_err(o[1][k], out[0][1][k]) < 2e-3, k
 
 
-def test_culled_groups_kernel_gives_the_fused_kernels_bits(dev):
-    """mi3dgs_adam_culled_groups against mi3dgs_project_bwd_adam restricted to the same groups (MI3DGS_FLAG_ONLY_CULLED_GROUPS): random
+@pytest.mark.parametrize("sreg", [0.0, 0.1])
+def test_culled_groups_kernel_gives_the_fused_kernels_bits(dev, sreg):
+    """(sreg: in a step with splatfacto's scale regulariser a culled Gaussian has that one gradient, formed by both kernels.)
+    mi3dgs_adam_culled_groups against mi3dgs_project_bwd_adam restricted to the same groups (MI3DGS_FLAG_ONLY_CULLED_GROUPS): random
     parameters and moments, groups of 64 marked culled / visible through the radii -- bit for bit on the culled groups, nothing
     touched elsewhere; including a last group of fewer than 64 Gaussians."""
     ops = _ops()
@@ -692,13 +694,17 @@ def test_culled_groups_kernel_gives_the_fused_kernels_bits(dev):
     P0, M0, V0 = fresh()
     P1, M1, V1 = fresh()
     P2, M2, V2 = fresh()
-    ops.adam_culled_groups(P1, M1, V1, lrs, 7, radii, n=N)
+    ops.adam_culled_groups(P1, M1, V1, lrs, 7, radii, n=N, scale_reg_weight=sreg, scale_reg_max_ratio=10.0)
     vm = torch.eye(4, device=dev)[None].contiguous()
     K = torch.tensor([[[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]]], device=dev)
     splats = torch.zeros(1, N, ops.SPLAT_STRIDE, device=dev)
     v_splats = torch.zeros(1, N, ops.GRAD_STRIDE, device=dev)
     ops.project_bwd_adam(P2, M2, V2, lrs, 7, vm, K, 64, 48, radii, splats, v_splats, n=N, sh_degree=3,
-                         flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC | ops.FLAG_ONLY_CULLED_GROUPS)
+                         flags=ops.FLAG_LOG_SCALES | ops.FLAG_LOGIT_OPAC | ops.FLAG_ONLY_CULLED_GROUPS, scale_reg_weight=sreg,
+                         scale_reg_max_ratio=10.0)
+    if sreg:        # the regulariser is active on a good part of them (log-scales ~ N(0, 1): ratio = exp(max - min))
+        sc0 = P0[2]
+        assert 0.2 < float(((sc0.amax(1) - sc0.amin(1)).exp() > 10.0).float().mean()) < 0.9
     assert int(culled.sum()) > 64 * 8 and int((~culled).sum()) > 64 * 8
     for a, b, z in zip(P1 + M1 + V1, P2 + M2 + V2, P0 + M0 + V0):
         assert torch.equal(a[culled], b[culled])                 # the two kernels: the same bits
