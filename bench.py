@@ -253,11 +253,11 @@ class StageTimer:
         return out
 
 
-def cpu_baseline_cpu_tensors(P, vm, K, gt, W, H, crop_div=6):
+def cpu_baseline_cpu_tensors(P, vm, K, gt, W, H, crop_div=4):
     """One training step of the CPU oracle (a port: the reference has no CPU rasteriser) on a
     bounded sample, timed in three legs so that the extrapolation is explicit:
       A  project + SH forward over ALL Gaussians             (scales with N, not with the frame)
-      B  binning + rasterise fwd + L1/SSIM + rasterise bwd on a centred (W/d x H/d) crop
+      B  binning + rasterise fwd + L1/SSIM + rasterise bwd on a centred (W/d x H/d) crop (d = 4: the 1/16 of SURVEY 8d)
       C  project + SH backward over ALL Gaussians
     full-frame step time = A + C + d*d * B.  Adam is not included (the oracle's is a 1-liner)."""
     from oracle import gs_oracle as O
