@@ -178,6 +178,9 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, 
     asm volatile("" ::: "memory");      // the rows were written by other lanes of this wave: LDS is in order per wave
     const u4v* ap = reinterpret_cast<const u4v*>(&L.tr[wv][lane & 15][4 * (lane >> 4)]);
     P.a[0] = ap[0]; P.a[1] = ap[4]; P.a[2] = ap[8]; P.a[3] = ap[12];
+    // (hipcc hoists the MFMAs between these reads to reuse one register quad for three of them: read, read, wait, MFMA, wait, MFMA,
+    //  read, wait, ...  Forcing all four reads in front of the first MFMA -- 16 registers, the prologue spills for it -- measured
+    //  WORSE: S2 313 -> 322 us, absgrad 484 -> 488, S1 103 -> 109; the first MFMA starts later and nothing else fills the wait.)
     asm volatile("" ::: "memory");      // the next chunk's stores stay behind these reads
     P.d = f4v{0.f, 0.f, 0.f, 0.f};
     P.slot0 = slot0;
