@@ -619,15 +619,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands, int n_workers,
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int n_workers,
     SegWs seg, const float* __restrict__ render) {
     __shared__ StagedBwdMM<ABSGRAD, SH> L;
     __shared__ int s_items;
     int item = (int)blockIdx.x < n_workers ? (int)blockIdx.x : -1;            // < 0: a tile's own block
     int t = -1, n_items = 0;
     if (item < 0) {
-        t = tile_of_block((int)blockIdx.x - n_workers, n_tiles_total, bands, tw);
-        if (t < 0) return;
+        t = (int)blockIdx.x - n_workers;
     } else {
         // The workers leave the counter clear for the next forward: one thread per worker reads it and counts itself in; the
         // last one to do so resets both words (every reader has read by then).  A clear per forward was a launch per step.
@@ -684,11 +683,11 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     //  estimate of how many intersections the caller expects)
     const bool many_items = seg.ckpt && (size_t)seg.cap > (size_t)n_tiles + 16 + SEG_MANY_ITEMS;
     const int n_workers = seg.ckpt ? (many_items ? SEG_WORKERS_MANY : SEG_WORKERS) : 0;
-    const int grid = raster_grid(n_tiles, tile_width) + n_workers;
+    const int grid = n_tiles + n_workers;
 #define LAUNCH_MM(BG, AG, T3, SH)                                                                                                 \
     MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, T3, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
-              v_render, v_alphas, v_splats, raster_bands(), n_workers, seg, render)
+              v_render, v_alphas, v_splats, n_workers, seg, render)
     // with the segment workspace no walk is longer than 512 entries and a launch is many short blocks whose fixed cost (three
     // dependent round trips, 11 - 16 us) is what the fourth resident block hides: WIDE then wins on the real-splat regime too
     // (wolf 960x720 125 -> 114 us, 1920x1080 256 -> 215; 640x480 92 -> 96), profiles/r03_raster_bwd_shape_ab.txt

@@ -220,38 +220,12 @@ __device__ __forceinline__ float alpha_of(float s) {
 constexpr int AC_QU = 0, AC_QV = 1, AC_QUU = 2, AC_QUV = 3, AC_QVV = 4, AC_Q = 5, AC_R = 6, AC_G = 7, AC_B = 8,
               AC_ABSX = 9, AC_ABSY = 10, AC_STRIDE = 12;
 
-// Block -> tile.  Workgroups go to the eight XCDs round-robin by workgroup id and every XCD has its own L2.  With tile =
-// blockIdx (the default) XCD k owns the tile COLUMNS x = k mod 8 (120 tiles per row at 1080p: t and t + 120 meet in one L2
-// and are resident together), and every XCD gets the same mix of heavy and light tiles.  MI3DGS_XCD_BANDS=1 gives XCD k one
-// contiguous eighth of the image instead: measured rasterize_fwd 129 -> 204 us, rasterize_bwd 487 -> 750 us -- the heavy
-// middle of the picture lands on three or four XCDs while the others idle.  Balance across XCDs beats locality within one.
-// bands == 2: clusters of 4 x 2 tiles, cluster c on XCD c mod 8, its eight tiles dispatched back to back (balance across the
-// XCDs AND neighbours in one L2); the grid is padded to whole clusters and rounds of eight clusters, -1 = no tile.
-__device__ __forceinline__ int tile_of_block(int b, int n_tiles, int bands, int tw) {
-    if (!bands) return b;
-    if (bands == 1) {
-        const int k = b & 7, j = b >> 3, q = n_tiles >> 3, r = n_tiles & 7;
-        return k * q + (k < r ? k : r) + j;
-    }
-    const int k = b & 7, j = b >> 3;
-    const int c = k + 8 * (j >> 3), within = j & 7;
-    const int cw = (tw + 3) >> 2;
-    const int cy = c / cw, cx = c - cy * cw;
-    const int tx = 4 * cx + (within & 3), ty = 2 * cy + (within >> 2);
-    const int t = ty * tw + tx;
-    return (tx < tw && t < n_tiles) ? t : -1;
-}
-inline int raster_bands() {
-    static const int v = [] { const char* e = MI_EXPERIMENT_ENV("MI3DGS_XCD_BANDS"); return e ? atoi(e) : 0; }();       // (experiments build only: both measured slower)
-    return v;
-}
-// blocks to launch for n_tiles tiles of a tw-wide tile grid
-inline int raster_grid(int n_tiles, int tw) {
-    if (raster_bands() != 2) return n_tiles;
-    const int cw = (tw + 3) / 4, rows = (n_tiles + tw - 1) / tw, ch = (rows + 1) / 2;
-    const int clusters = cw * ch;
-    return 64 * ((clusters + 7) / 8);
-}
+// Block -> tile: tile = block.  Workgroups go to the eight XCDs round-robin by workgroup id and every XCD has its own L2, so XCD k
+// owns the tile COLUMNS x = k mod 8 (120 tiles per row at 1080p: t and t + 120 meet in one L2 and are resident together) and
+// every XCD gets the same mix of heavy and light tiles.  Two other mappings were measured in round 2 and removed in round 4
+// (docs/FINDINGS_r01_r02.md): one contiguous eighth of the image per XCD (rasterize_fwd 129 -> 204 us, rasterize_bwd 487 -> 750:
+// the heavy middle of the picture lands on three or four XCDs) and clusters of 4 x 2 tiles per XCD (slower too).  Balance
+// across XCDs beats locality within one.
 
 struct PixelBasis { float u, v, uu, uv, vv; };
 

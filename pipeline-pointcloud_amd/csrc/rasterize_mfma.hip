@@ -39,11 +39,10 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alphas,
-    int32_t* __restrict__ last_ids, int bands, SegWs seg) {
+    int32_t* __restrict__ last_ids, SegWs seg) {
     __shared__ Staged L;
     __shared__ uint32_t s_slot;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
-    if (t < 0) return;
+    const int t = (int)blockIdx.x;
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_seg_kernel(int W, int H, 
                                                                   const int32_t* __restrict__ flatten_ids,
                                                                   const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
                                                                   const float* __restrict__ backgrounds, float* __restrict__ render,
-                                                                  float* __restrict__ alphas, int32_t* __restrict__ last_ids, int bands,
+                                                                  float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                                   int n_workers, SegWs seg) {
     __shared__ Staged L;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -302,8 +301,7 @@ __global__ __launch_bounds__(BLOCK) void rasterize_fwd_seg_kernel(int W, int H, 
         RF_STAMP(1, wall_clock64());
         return;
     }
-    const int t = tile_of_block((int)blockIdx.x - n_workers, n_tiles_total, bands, tw);
-    if (t < 0) return;
+    const int t = (int)blockIdx.x - n_workers;
     const int start = tile_offsets[t];
     const int end = (t + 1 < n_tiles_total) ? tile_offsets[t + 1] : *n_isect_ptr;
     if (end - start > SEG_MIN) return;                         // in segments: the workers and the combine pass
@@ -516,10 +514,9 @@ __global__ __launch_bounds__(BLOCK) void rasterize_bwd_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int bands) {
+    const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
     __shared__ StagedBwd L;
-    const int t = tile_of_block((int)blockIdx.x, n_tiles_total, bands, tw);
-    if (t < 0) return;
+    const int t = (int)blockIdx.x;
     const int cam = t / (tw * th);
     const int tile_in = t - cam * (tw * th);
     const int ty = tile_in / tw, tx = tile_in - ty * tw;
@@ -681,9 +678,9 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
         const int n_workers = (int)min((size_t)FWD_SEG_WORKERS, (size_t)seg.cap);
         MI_LAUNCH("rasterize_fwd_plan", fwd_plan_kernel, dim3(1), dim3(1024), 0, st, isect_offsets, n_isect_dev, n_tiles, seg);
 #define LAUNCH_SEG(BG)                                                                                                    \
-    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_seg_kernel<BG>), dim3(n_workers + raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width,        \
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_seg_kernel<BG>), dim3(n_workers + n_tiles), dim3(BLOCK), 0, st, width,        \
               height, tile_width, tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, \
-              raster_bands(), n_workers, seg);                                                                               \
+              n_workers, seg);                                                                               \
     MI_LAUNCH("rasterize_fwd_combine", fwd_combine_kernel<BG>, dim3(512), dim3(BLOCK), 0, st, width, height, tile_width, tile_height,           \
               backgrounds, render, alphas, last_ids, seg);                                                                   \
     MI_LAUNCH("rasterize_fwd_finish", fwd_finish_kernel<BG>, dim3(n_workers), dim3(BLOCK), 0, st, width, height, tile_width, tile_height, splats, \
@@ -694,8 +691,8 @@ int mi_rasterize_fwd_mfma(int n_tiles, int width, int height, int tile_width, in
         return 0;
     }
 #define LAUNCH_FWD(BG)                                                                                                    \
-    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width,     \
-              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, raster_bands(), seg)
+    MI_LAUNCH("rasterize_fwd", (rasterize_fwd_kernel<BG>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width,     \
+              tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, render, alphas, last_ids, seg)
     if (backgrounds) LAUNCH_FWD(true); else LAUNCH_FWD(false);
 #undef LAUNCH_FWD
     MI_LAUNCH_CHECK();
@@ -720,9 +717,9 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
 #ifdef MI3DGS_EXPERIMENTS
     if (mode == 3) {
 #define LAUNCH_BWD(BG, AG)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, false>), dim3(raster_grid(n_tiles, tile_width)), dim3(BLOCK), 0, st, width, height, tile_width, \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_kernel<BG, AG, false>), dim3(n_tiles), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
-              v_render, v_alphas, v_splats, raster_bands())
+              v_render, v_alphas, v_splats)
         if (backgrounds) { if (absgrad) LAUNCH_BWD(true, true); else LAUNCH_BWD(true, false); }
         else { if (absgrad) LAUNCH_BWD(false, true); else LAUNCH_BWD(false, false); }
 #undef LAUNCH_BWD
