@@ -76,7 +76,6 @@ int mi3dgs_adam_culled_groups(int N, float* const* params, float* const* exp_avg
  *   MI3DGS_OS_MAX_KEYS        sorts above this many keys use the classic radix passes (default 4 M)
  *   MI3DGS_EMIT_SMALL_SPLATS  up to this many Gaussians the tile emit gives a wave 16 splats instead of 64 (default 256 K)
  *   MI3DGS_KEYS16=0           never sort 16-bit tile keys
- *   MI3DGS_BWD_WIDE_MIN       from this many Gaussians on, rasterize_bwd runs its four-waves-per-SIMD shape (default 200 000)
  * Everything that can return wrong results (timing experiments) and every rejected variant is compiled only into
  * libmi3dgs_exp.so (make -C csrc: -DMI3DGS_EXPERIMENTS), which the product never loads. */
 const char* mi3dgs_last_error(void);

@@ -25,10 +25,10 @@ static int g_raster_mode = 1;
 // Mode 1 = the product kernels, the only mode the product library has.  The experiments build (libmi3dgs_exp.so) adds:
 // 3 = MFMA forward + backward with the all-f32 cross-lane reduce-scatter instead of the bf16 MFMA contraction (correct; the f32
 // yardstick of tests/test_gpu_configs.py and of the precision A/B); 4 = backward with THREE-term bf16 pixel sums (24 significant
-// bits); 21 / 22 = the product backward forced to its DEEP / WIDE shape.  Forward and backward must run in the same mode.
+// bits).  Forward and backward must run in the same mode.
 extern "C" int mi3dgs_debug_set_raster_mode(int mode) {
 #ifdef MI3DGS_EXPERIMENTS
-    MI_REQUIRE(mode == 1 || mode == 3 || mode == 4 || mode == 21 || mode == 22,
+    MI_REQUIRE(mode == 1 || mode == 3 || mode == 4,
                "set_raster_mode: unknown mode");
     g_raster_mode = mode;
     return 0;

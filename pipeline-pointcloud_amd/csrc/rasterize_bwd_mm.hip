@@ -48,19 +48,13 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int TR_ROWS = 16;
 constexpr int GRP = 64;                   // slots per flush group: the per-wave sums of 64 splats wait in LDS, then the block flushes them
 constexpr int AW = 12;                    // floats per (wave, slot) sum row: 48 bytes, read by the flush as three float4
-// ---- two shapes of the kernel, chosen per launch by the number of Gaussians (mi_rasterize_bwd_mm):
-//   STG        splats per staged batch: 256 (one per thread) or 128 (LDS 50 -> 40 KB: room for four blocks per CU)
-//   PIPELINE   true: a chunk's contraction is issued one MFMA per visit among the NEXT chunk's visits (16 + 4 more live
-//              registers); false: operands are read and the four MFMAs issued when the chunk ends
-//   WAVES      waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128)
-// DEEP = the round-2 kernel: fastest per wave, three waves per SIMD.  WIDE: 128 registers, 40 KB, four waves per SIMD.
-// Same-box A/B (profiles/r03_raster_bwd_shape_ab.txt, tools/raster_ab.py): S2 (2 M Gaussians, every tile a few hundred
-// reached splats) 459 -> 398 us with WIDE; S1 148 -> 144; the reference's wolf.spz at 960 x 720 (100 k Gaussians, the time is the
-// serial walk of a few hundred heavy tiles) 201 -> 205, with absgrad 271 -> 288: there a wave's own speed counts, not how many
-// waves wait beside it.  WIDE by the compiler's spiller instead (pipelining kept, 39 registers in scratch) LOST 8 - 15 %
-// (r03_raster_bwd_occupancy_ab.txt); WIDE's ingredients at three waves (no pipelining, 256-slot batches) lose 3 - 5 %.
-struct ShapeDeep { static constexpr int STG = 256, WAVES = 3; static constexpr bool PIPELINE = true; };
-struct ShapeWide { static constexpr int STG = 128, WAVES = 4; static constexpr bool PIPELINE = false; };
+// ---- ONE shape: staged batches of 128 splats, 128 registers, 40 KB of LDS = four blocks per CU, four waves per SIMD; a chunk's
+// operands are read and its four MFMAs issued when the chunk ends.  Rounds 2 - 3 also had a DEEP shape (256-splat batches, the
+// contraction software-pipelined one MFMA per visit into the NEXT chunk's visits through 20 more live registers, 168 registers,
+// three waves per SIMD): 12 % slower on S2, a tie on S1, 2 - 6 % faster only on ~100 k real splats WITHOUT the segment
+// workspace -- a case training never runs (profiles/r03_raster_bwd_shape_ab.txt).  Removed in round 4 with its launcher rule.
+constexpr int STG = 128;                  // splats per staged batch
+constexpr int BWD_WAVES = 4;              // waves per SIMD the register allocation is held to
 // columns of a per-wave sum row: the nine of the reduce-scatter kernel (AC_*), then, without ABSGRAD, the lo part of the colour
 // sums (9..11; the flush adds them); with ABSGRAD the lo colour sums are added to the hi ones before they are stored (one DPP
 // step in mm_finish) and |x|, |y| take columns 9, 10.
@@ -69,9 +63,8 @@ constexpr int ABS_COL_X = 9, ABS_COL_Y = 10;
 // LDS float atomics are lane-serial on this part (tools/micro/lds_ops.hip: ds_add_f32 takes ~3 LDS cycles per ACTIVE lane,
 // 55 for the 18 lanes that would add a chunk's sums, against 3 for a plain ds_write_b32), so every wave keeps its own sums
 // (plain stores, each (wave, slot, column) written at most once per group) and the flush adds the four quadrants.
-template <bool ABSGRAD, typename SH>
+template <bool ABSGRAD>
 struct StagedBwdMM {
-    static constexpr int STG = SH::STG;
     // words per transposition row.  (68 puts rows 11 and 12 of a ds_read_b128's 16-lane groups on one bank; 72 is conflict-free for
     // that read and measured the same to 0.1 % on S2, S1 and wolf -- the reads are not what the kernel waits for -- so the smaller one stays.)
     static constexpr int TRS = 68;
@@ -130,15 +123,11 @@ __device__ __forceinline__ void split3w(float a, unsigned& wA, unsigned& wB) {
     wB = l;
 }
 
-// DEEP: the contraction of a chunk is software-pipelined against the visits of the NEXT chunk: its A operands are read when its
-// last visit has stored (LDS executes a wave's instructions in order, so the next chunk's stores to the same rows stay behind
-// these reads), its 4 MFMAs are issued one per visit between the vector instructions of the following visits, and its
-// sums are stored when that chunk ends.  At a sub-batch boundary a pending chunk has its operands and none of its MFMAs.
+// the contraction of one chunk: operands, accumulator, first slot of the chunk inside its group
 struct MMPend {
     u4v a[4];
     f4v d;
-    int slot0;                // first slot of the chunk inside its group
-    bool on;                  // wave-uniform
+    int slot0;
 };
 
 __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
@@ -148,8 +137,8 @@ __device__ __forceinline__ void mm_issue(MMPend& P, const MMLane& mm, int m) {
 // Row layout of a chunk (T3 = the three-term experiment keeps the round-3 layout, kind-major):
 //   plain:    row 2 c + kind,  kind = Q, W             -> D row 4 g + r is splat 2 g + (r >> 1), kind r & 1
 //   ABSGRAD:  row 4 c + kind,  kind = Q, W, |x|, |y|   -> D row 4 g + r is splat g, kind r
-template <bool ABSGRAD, bool T3, typename SH>
-__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
+template <bool ABSGRAD, bool T3>
+__device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
     const int j = lane & 15;
     float* a = &L.accw[wv][P.slot0][0];
     if (T3) {
@@ -170,11 +159,10 @@ __device__ __forceinline__ void mm_finish(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P
         a[mm.acc_off] = j < 6 ? P.d[0] : P.d[1];
         a[mm.acc_off + AW] = j < 6 ? P.d[2] : P.d[3];
     }
-    P.on = false;
 }
 
-template <bool ABSGRAD, typename SH>
-__device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, int wv, int lane, int slot0) {
+template <bool ABSGRAD>
+__device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD>& L, MMPend& P, int wv, int lane, int slot0) {
     asm volatile("" ::: "memory");      // the rows were written by other lanes of this wave: LDS is in order per wave
     const u4v* ap = reinterpret_cast<const u4v*>(&L.tr[wv][lane & 15][4 * (lane >> 4)]);
     P.a[0] = ap[0]; P.a[1] = ap[4]; P.a[2] = ap[8]; P.a[3] = ap[12];
@@ -184,15 +172,13 @@ __device__ __forceinline__ void mm_read(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, 
     asm volatile("" ::: "memory");      // the next chunk's stores stay behind these reads
     P.d = f4v{0.f, 0.f, 0.f, 0.f};
     P.slot0 = slot0;
-    P.on = true;
 }
 
-template <bool ABSGRAD, bool T3, typename SH>
-__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD, SH>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
-    if (!P.on) return;
+template <bool ABSGRAD, bool T3>
+__device__ __forceinline__ void mm_drain(StagedBwdMM<ABSGRAD>& L, MMPend& P, const MMLane& mm, int wv, int lane) {
 #pragma unroll
     for (int m = 0; m < 4; m++) mm_issue(P, mm, m);
-    mm_finish<ABSGRAD, T3, SH>(L, P, mm, wv, lane);
+    mm_finish<ABSGRAD, T3>(L, P, mm, wv, lane);
 }
 
 // what lane l holds of splat (l & 31) of the sub-batch: handed to the visits by v_readlane
@@ -202,8 +188,8 @@ __device__ __forceinline__ float lane_bcast(float v, int i) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
 }
 
-template <bool ABSGRAD, typename SH>
-__device__ __forceinline__ SubUni load_sub_uni(const StagedBwdMM<ABSGRAD, SH>& L, int sb, int lane) {
+template <bool ABSGRAD>
+__device__ __forceinline__ SubUni load_sub_uni(const StagedBwdMM<ABSGRAD>& L, int sb, int lane) {
     SubUni U = {};
     const int k = sb * SUB + (lane & 31);
     const float4 c = L.f.uni[k];
@@ -218,15 +204,15 @@ __device__ __forceinline__ SubUni load_sub_uni(const StagedBwdMM<ABSGRAD, SH>& L
 // One sub-batch of the backward walk, rows i = 0..31 <-> sorted indices be - 32 sb - i (back to front).
 // FAST: every pixel of the wave composited something and is already in range (index <= its last contributor), and none of the
 // sub-batch's splats can reach the 0.999 clamp (the caller's test): a visit's membership test is the threshold compare alone.
-template <bool ABSGRAD, bool FAST, bool T3_, typename SH>
-__device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
+template <bool ABSGRAD, bool FAST, bool T3_>
+__device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD>& L, const float (&s)[SUB], int sb, int be, int lane, int wv,
                                                  int bin_final, unsigned long long has, const PixelBasis& px, const MMLane& mm,
                                                  MMPend& P, unsigned long long& gmask, const float (&vrgb)[3],
                                                  float& T, float& bd, const SubUni& U) {
     constexpr bool T3 = T3_ && !ABSGRAD;         // three-term transport (experiments build)
     constexpr int CH = (ABSGRAD || T3) ? 4 : 8;  // splats per chunk: CH x (2 or 4 values) = 16 rows
     constexpr int KINDS = 16 / CH;
-    constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD, SH>::TRS;
+    constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD>::TRS;
     const int gs0 = (sb * SUB) & (GRP - 1);      // slot of row 0 inside its group
     unsigned* trw = &L.tr[wv][0][lane];
     // This loop is bound by the instructions ONE wave can issue (about one per four cycles, whatever their kind), so scalar
@@ -238,7 +224,6 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, co
     for (int i = 0; i < SUB; i++) {
         const int k = sb * SUB + i;
         const int ci = i % CH;
-        if (SH::PIPELINE && ci < 4) mm_issue(P, mm, ci);         // of the chunk before (results unused if there was none)
         // the forward's own membership test (same MFMA result, same compare), for the splats this pixel reached
         unsigned long long valid = mask_ge(s[i], LOG2_ALPHA_THRESHOLD);
         if (!FAST) valid &= has & mask_ge_i(bin_final, be - k);
@@ -289,11 +274,10 @@ __device__ __forceinline__ void bwd_sub_batch_mm(StagedBwdMM<ABSGRAD, SH>& L, co
             }
         }
         if (ci == CH - 1) {
-            if (SH::PIPELINE && P.on) mm_finish<ABSGRAD, T3, SH>(L, P, mm, wv, lane);
             const unsigned cl = (live >> (i - (CH - 1))) & ((1u << CH) - 1u);
-            if (cl) {
-                mm_read<ABSGRAD, SH>(L, P, wv, lane, gs0 + i - (CH - 1));
-                if (!SH::PIPELINE) mm_drain<ABSGRAD, T3, SH>(L, P, mm, wv, lane);      // read, four MFMAs, store: nothing stays live
+            if (cl) {           // read, four MFMAs, store: nothing stays live across visits
+                mm_read<ABSGRAD>(L, P, wv, lane, gs0 + i - (CH - 1));
+                mm_drain<ABSGRAD, T3>(L, P, mm, wv, lane);
             }
         }
     }
@@ -321,8 +305,8 @@ namespace mfma_raster {
 // The flush this replaces (rounds 2, 3) gave every slot sixteen lanes that each summed one column, fetched M, Mu, Mv and a
 // fourth value from their neighbours through ds_bpermute and ran an eleven-way switch on their component: ~120 instructions
 // per round of 16 slots.
-template <bool ABSGRAD, typename SH>
-__device__ __forceinline__ void flush_group_lane_per_slot(StagedBwdMM<ABSGRAD, SH>& L, int wv, int lane, int g0, int bsz,
+template <bool ABSGRAD>
+__device__ __forceinline__ void flush_group_lane_per_slot(StagedBwdMM<ABSGRAD>& L, int wv, int lane, int g0, int bsz,
                                                           float* __restrict__ v_splats) {
     constexpr int OUT_STRIDE = 20;            // floats per output row: 16-byte aligned, and 20 l mod 64 keeps eight rows' float4 stores on disjoint banks
     constexpr int NCOMP = ABSGRAD ? GR_DEPTH : GR_ABSX;
@@ -392,13 +376,12 @@ __device__ __forceinline__ void flush_group_lane_per_slot(StagedBwdMM<ABSGRAD, S
 // One walk of rasterize_bwd: the entries [lo, ...] of tile t's list, back to front, for the block's 256 pixels.
 //   item < 0: the tile's own block -- everything behind the last boundary the forward left (the whole list if it left none);
 //   item >= 0: segment `item` of the work list -- the entries in front of a boundary, state from the forward's checkpoint.
-template <bool HAS_BG, bool ABSGRAD, bool T3, typename SH>
-__device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int item, const SegWs& seg, const float* __restrict__ render,
+template <bool HAS_BG, bool ABSGRAD, bool T3>
+__device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD>& L, int t, int item, const SegWs& seg, const float* __restrict__ render,
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats) {
-    constexpr int STG = SH::STG;
     const bool worker = item >= 0;
     int seg_lo = 0, seg_len = 0;
     uint32_t slot_ck = 0;
@@ -500,7 +483,7 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
         // each lane worked the sixteen values out itself -- pixel coordinates, selects by column, conversions, sixteen times over:
         // ~640 VALU instructions, 7.1 us of a short block's 16.2 at four waves per SIMD; tools/raster_ab.py probe.)
         {
-            constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD, SH>::TRS;
+            constexpr int TR_STRIDE = StagedBwdMM<ABSGRAD>::TRS;
             unsigned* const trw = &L.tr[wv][0][lane];
             const float bas[6] = {px.u, px.v, px.uu, px.uv, px.vv, 1.f};
 #pragma unroll
@@ -540,7 +523,6 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 
     const unsigned long long has = wave_ballot(bin_final >= 0);
     MMPend P;
-    P.on = false;
     RB_STAMP(3, wall_clock64()); RB_STAMP(4, 0ull); RB_STAMP(5, 0ull);
     for (int be = bmax; be >= start; be -= STG) {
         __syncthreads();
@@ -572,10 +554,10 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
             for (int sb = g0 / SUB; sb < g0 / SUB + GRP / SUB; sb++) {
                 if (sb * SUB >= bsz || sb < k0 / SUB) continue;
                 float s[SUB];
-                const SubUni U = load_sub_uni<ABSGRAD, SH>(L, sb, lane);       // (in front of the MFMAs: their latency covers the reads)
-                if (ABSGRAD && !SH::PIPELINE) {
-                    // the alpha basis rebuilt here instead of held across the visits: ten registers that let hipcc keep ABSGRAD's
-                    // WIDE instance at 128 without spilling (plain: 305 -> 314 us, ABSGRAD 474 -> 471; only the latter takes it)
+                const SubUni U = load_sub_uni<ABSGRAD>(L, sb, lane);       // (in front of the MFMAs: their latency covers the reads)
+                if (ABSGRAD) {
+                    // the alpha basis rebuilt here instead of held across the visits: ten registers that let hipcc keep the ABSGRAD
+                    // instance at 128 without spilling (plain: 305 -> 314 us, ABSGRAD 474 -> 471; only the latter takes it)
                     int wv_ = wv, lane_ = lane;
                     asm volatile("" : "+v"(wv_), "+v"(lane_));
                     eval_sub_batch(L.f, sb, lane, make_basis(wv_, lane_), s);
@@ -586,15 +568,14 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
                 asm volatile("" :: "v"(U.r), "v"(U.g), "v"(U.b));
                 if (ABSGRAD) asm volatile("" :: "v"(U.A), "v"(U.B), "v"(U.C), "v"(U.ax), "v"(U.ay));
                 if (be - sb * SUB <= wmin && has == ~0ull && !L.hot[sb])
-                    bwd_sub_batch_mm<ABSGRAD, true, T3, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
+                    bwd_sub_batch_mm<ABSGRAD, true, T3>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
                 else
-                    bwd_sub_batch_mm<ABSGRAD, false, T3, SH>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
+                    bwd_sub_batch_mm<ABSGRAD, false, T3>(L, s, sb, be, lane, wv, bin_final, has, px, mm, P, gmask, vrgb, T, bd, U);
             }
-            mm_drain<ABSGRAD, T3 && !ABSGRAD, SH>(L, P, mm, wv, lane);
             if (lane == 0) L.gmask[wv] = gmask;
             __syncthreads();
             if (be == bmax && g0 == 0) RB_STAMP(5, wall_clock64());
-            flush_group_lane_per_slot<ABSGRAD, SH>(L, wv, lane, g0, bsz, v_splats);
+            flush_group_lane_per_slot<ABSGRAD>(L, wv, lane, g0, bsz, v_splats);
             __syncthreads();
         }
     }
@@ -614,14 +595,14 @@ __device__ __forceinline__ void bwd_walk(StagedBwdMM<ABSGRAD, SH>& L, int t, int
 constexpr int SEG_WORKERS = 512, SEG_WORKERS_MANY = 1024;
 constexpr size_t SEG_MANY_ITEMS = 4096;      // workspace sized for more than a million intersections
 
-template <bool HAS_BG, bool ABSGRAD, bool T3, typename SH>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES, SH::WAVES))) void rasterize_bwd_mm_kernel(
+template <bool HAS_BG, bool ABSGRAD, bool T3>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, BWD_WAVES))) void rasterize_bwd_mm_kernel(
     int W, int H, int tw, int th, const float* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ n_isect_ptr, int n_tiles_total,
     const float* __restrict__ backgrounds, const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alphas, float* __restrict__ v_splats, int n_workers,
     SegWs seg, const float* __restrict__ render) {
-    __shared__ StagedBwdMM<ABSGRAD, SH> L;
+    __shared__ StagedBwdMM<ABSGRAD> L;
     __shared__ int s_items;
     int item = (int)blockIdx.x < n_workers ? (int)blockIdx.x : -1;            // < 0: a tile's own block
     int t = -1, n_items = 0;
@@ -646,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
             if (item >= n_items) return;
             __syncthreads();                             // the walk before may still be reading L
         }
-        bwd_walk<HAS_BG, ABSGRAD, T3, SH>(L, t, item, seg, render, W, H, tw, th, splats, tile_offsets, flatten_ids, n_isect_ptr,
+        bwd_walk<HAS_BG, ABSGRAD, T3>(L, t, item, seg, render, W, H, tw, th, splats, tile_offsets, flatten_ids, n_isect_ptr,
                                           n_tiles_total, backgrounds, alphas, last_ids, v_render, v_alphas, v_splats);
         if (item < 0) return;
         item += n_workers;
@@ -655,18 +636,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SH::WAVES
 
 }  // namespace mfma_raster
 
-// Which shape: WIDE (four waves per SIMD) where many blocks of similar weight keep every CU busy, DEEP (fastest single wave)
-// where a few heavy tiles decide -- which, with the segment workspace, no longer happens (see the launcher).  The host knows neither list lengths nor reached fractions without a sync; it knows the number
-// of Gaussians in the call, and the regimes measured separate on it (2 M and 300 k: WIDE wins by 13 % and 3 %; 100 k real
-// splats: DEEP wins by 2 - 6 %).  MI3DGS_BWD_WIDE_MIN moves the switch-over (documented tuning knob, include/mi3dgs.h).
-static long long bwd_wide_min() {
-    static const long long v = [] { const char* e = getenv("MI3DGS_BWD_WIDE_MIN"); return e ? atoll(e) : 200000ll; }();
-    return v;
-}
-
 // experiment: 0 = the product kernel, the only one the product library holds.  Experiments build (libmi3dgs_exp.so):
 // 4 = three-term transport of the pixel sums (24 significant bits; the precision A/B of profiles/r03_bwd_terms_ab.txt and
-// profiles/r04_precision_ab.txt), 21 / 22 = force the DEEP / WIDE shape.
+// profiles/r04_precision_ab.txt).
 int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int tile_height, long long n_gauss, const float* splats,
                         const int32_t* isect_offsets, const int32_t* flatten_ids, const int32_t* n_isect_dev,
                         const float* backgrounds, const float* alphas, const int32_t* last_ids, const float* v_render,
@@ -684,30 +656,21 @@ int mi_rasterize_bwd_mm(int n_tiles, int width, int height, int tile_width, int 
     const bool many_items = seg.ckpt && (size_t)seg.cap > (size_t)n_tiles + 16 + SEG_MANY_ITEMS;
     const int n_workers = seg.ckpt ? (many_items ? SEG_WORKERS_MANY : SEG_WORKERS) : 0;
     const int grid = n_tiles + n_workers;
-#define LAUNCH_MM(BG, AG, T3, SH)                                                                                                 \
-    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, T3, SH>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
+#define LAUNCH_MM(BG, AG, T3)                                                                                                     \
+    MI_LAUNCH("rasterize_bwd", (rasterize_bwd_mm_kernel<BG, AG, T3>), dim3(grid), dim3(BLOCK), 0, st, width, height, tile_width, \
               tile_height, splats, isect_offsets, flatten_ids, n_isect_dev, n_tiles, backgrounds, alphas, last_ids,        \
               v_render, v_alphas, v_splats, n_workers, seg, render)
-    // with the segment workspace no walk is longer than 512 entries and a launch is many short blocks whose fixed cost (three
-    // dependent round trips, 11 - 16 us) is what the fourth resident block hides: WIDE then wins on the real-splat regime too
-    // (wolf 960x720 125 -> 114 us, 1920x1080 256 -> 215; 640x480 92 -> 96), profiles/r03_raster_bwd_shape_ab.txt
-    bool wide = n_gauss >= bwd_wide_min() || seg.ckpt != nullptr;
 #ifdef MI3DGS_EXPERIMENTS
-    if (experiment == 21 || experiment == 22) { wide = experiment == 22; experiment = 0; }
     if (experiment == 4 && !absgrad) {           // three-term transport of the pixel sums (correct results, 24 significant bits)
-        if (backgrounds) LAUNCH_MM(true, false, true, ShapeDeep); else LAUNCH_MM(false, false, true, ShapeDeep);
+        if (backgrounds) LAUNCH_MM(true, false, true); else LAUNCH_MM(false, false, true);
         MI_LAUNCH_CHECK();
         return 0;
     }
 #endif
     MI_REQUIRE(experiment == 0, "rasterize_bwd: unknown variant");
-    if (wide) {
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, false, ShapeWide); else LAUNCH_MM(true, false, false, ShapeWide); }
-        else { if (absgrad) LAUNCH_MM(false, true, false, ShapeWide); else LAUNCH_MM(false, false, false, ShapeWide); }
-    } else {
-        if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, false, ShapeDeep); else LAUNCH_MM(true, false, false, ShapeDeep); }
-        else { if (absgrad) LAUNCH_MM(false, true, false, ShapeDeep); else LAUNCH_MM(false, false, false, ShapeDeep); }
-    }
+    (void)n_gauss;
+    if (backgrounds) { if (absgrad) LAUNCH_MM(true, true, false); else LAUNCH_MM(true, false, false); }
+    else { if (absgrad) LAUNCH_MM(false, true, false); else LAUNCH_MM(false, false, false); }
 #undef LAUNCH_MM
     MI_LAUNCH_CHECK();
     return 0;

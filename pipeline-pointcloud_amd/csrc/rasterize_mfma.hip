@@ -712,8 +712,8 @@ int mi_rasterize_bwd_mfma(int n_tiles, int width, int height, int tile_width, in
                           void* seg_ws, size_t seg_ws_bytes, hipStream_t st) {
     using namespace mfma_raster;
     // mode 1: the contraction on the matrix pipe (rasterize_bwd_mm.hip), the product path and the only one of the product
-    // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 / 21 / 22 = variants of the product
-    // kernel (rasterize_bwd_mm.hip: three-term sums, forced shapes)
+    // library.  Experiments build: 3 = cross-lane reduce-scatter in f32 (this file), 4 = the product kernel with three-term
+    // sums (rasterize_bwd_mm.hip)
 #ifdef MI3DGS_EXPERIMENTS
     if (mode == 3) {
 #define LAUNCH_BWD(BG, AG)                                                                                                 \

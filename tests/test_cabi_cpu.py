@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(built):
     assert built.lib().mi3dgs_splat_stride() == 16 and built.lib().mi3dgs_grad_stride() == 16
 
 
-TUNING_KNOBS = {"MI3DGS_OS_SMALL_KEYS", "MI3DGS_OS_MAX_KEYS", "MI3DGS_EMIT_SMALL_SPLATS", "MI3DGS_KEYS16", "MI3DGS_BWD_WIDE_MIN"}      # include/mi3dgs.h
+TUNING_KNOBS = {"MI3DGS_OS_SMALL_KEYS", "MI3DGS_OS_MAX_KEYS", "MI3DGS_EMIT_SMALL_SPLATS", "MI3DGS_KEYS16"}      # include/mi3dgs.h
 
 
 def _env_names(path):
