@@ -547,7 +547,7 @@ def main():
                 tr.step(i % V)
             prof = _lib.profile_read()
             _lib.profile_enable(False)
-            # ALGORITHMIC bytes per launch (BASELINE.md section 3 / DESIGN.md "Kernels"):
+            # ALGORITHMIC bytes per launch (BASELINE.md section 3 / DESIGN.md section 4):
             # I intersections, n Gaussians, n_vis visible, Px pixels
             I = n_isect
             # bytes of a tile key: 2 when the library sorts 16-bit keys (the step does not read the keys back, every tile id

@@ -268,7 +268,7 @@ int mi3dgs_debug_set_raster_mode(int mode);
  * side (four launches: plan; segments + short tiles; combine; the segments pixels stop in, once more).  Results agree to float
  * rounding (T_in * prod(1 - alpha) is associated differently; a pixel whose transmittance comes within an ulp of the 1e-4 stop may
  * end one segment early: bounded by 1e-4 in colour).  Halves the forward where lists are walked to their ends; slower where the
- * pixels saturate early, which is most of training.  The backward is the same either way. */
+ * pixels saturate early, which is most of training (docs/FINDINGS_r03.md 4.2).  The backward is the same either way. */
 int mi3dgs_debug_set_raster_fwd_segments(int on);
 
 /* ---- loss ----------------------------------------------------------------------------

@@ -298,7 +298,7 @@ def main_ns_train(argv: Optional[List[str]] = None) -> int:
     mcmc = a["model"] == "splatfacto-mcmc"
     cap = int(float(a["opts"].get("--max-gaussians", 1_000_000 if mcmc else 8_000_000)))   # splatfacto-mcmc max_gs_num 1e6
     import dataclasses
-    # --mi3dgs.raster-segments False: this engine's own switch (A/B of the segmented backward); not an upstream option
+    # --mi3dgs.raster-segments False: this engine's own switch (A/B of the segmented backward, docs/FINDINGS_r03.md 4.2); not an upstream option
     seg = str(a["opts"].get("--mi3dgs.raster-segments", "True")).lower() == "true"
     tr, ds, stats = run_training(a["data"], a["downscale"], lambda ds: dataclasses.replace(splatfacto_config(
         a["model"], a["max_steps"], a["scale_reg"], max(1, len(ds.train_idx)), cap), raster_segments=seg),

@@ -90,7 +90,7 @@ class TrainConfig:
     raster_segments: bool = True
     # ... and the forward walks lists longer than 256 entries as segments side by side (process-wide switch of the library).
     # Pays where the lists are walked to their ends (renders of an MCMC-trained model: 555 -> 283 us); in training the serial walk's
-    # stop at saturation is worth more (-4 .. -11 % of the step rate with this on)
+    # stop at saturation is worth more (-4 .. -11 % of the step rate with this on, docs/FINDINGS_r03.md 4.2)
     raster_fwd_segments: bool = False
     # order the initial Gaussians along a Morton curve of their positions (a permutation: same training up to float summation
     # order).  Neighbours in memory are then neighbours in space: a wave of the projection kernels is culled or visible as a

@@ -1,5 +1,5 @@
 """Every C-ABI entry that takes per-Gaussian or per-intersection arrays, with EVERY input, output and workspace ending at the end
-of a device allocation of its own.
+of a device allocation of its own (docs/FINDINGS_r03.md 3b).
 
 The kernels launch whole 256-thread blocks over N Gaussians and several of them use a "load first, clamp the index" idiom; an idle
 lane whose clamped index is computed wrongly reads behind its array.  Inside a caching allocator's segment that read hits

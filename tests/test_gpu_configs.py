@@ -376,7 +376,7 @@ def test_backward_in_segments_agrees_with_the_serial_walk_at_full_size(dev, kind
 
 
 def _wolf_frame(dev, opacity_scale):
-    """The real-training regime of DESIGN.md 4.2: the reference's wolf.spz inside an opaque shell, 960 x 720 (tools/train_wolf.py)."""
+    """The real-training regime of docs/FINDINGS_r03.md 4.2: the reference's wolf.spz inside an opaque shell, 960 x 720 (tools/train_wolf.py)."""
     import math
     from helpers import load_wolf
     from mi3dgs import scenes
